@@ -1,0 +1,233 @@
+"""ctypes binding of the CPU oracle (oracle/libpt_oracle.so) + fixture loaders.
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg (oracle/pt_oracle.h explains the rule)."""
+import ctypes as C
+import json
+import os
+import struct
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+
+class Material(C.Structure):
+    _fields_ = [("color", C.c_float * 3), ("specularExponent", C.c_float), ("specularColor", C.c_float * 3),
+                ("hasReflective", C.c_float), ("hasRefractive", C.c_float), ("indexOfRefraction", C.c_float),
+                ("hasScatter", C.c_float), ("absorptionCoefficient", C.c_float * 3),
+                ("reducedScatterCoefficient", C.c_float), ("emittance", C.c_float)]
+
+
+class Geom(C.Structure):
+    _fields_ = [("type", C.c_int), ("materialid", C.c_int), ("transform", C.c_float * 16),
+                ("inverseTransform", C.c_float * 16)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("resolution", C.c_float * 2), ("position", C.c_float * 3), ("view", C.c_float * 3),
+                ("up", C.c_float * 3), ("fov", C.c_float * 2)]
+
+
+class Config(C.Structure):
+    _fields_ = [("max_depth", C.c_int), ("camera_mode", C.c_int), ("antialias", C.c_int),
+                ("aperture", C.c_float), ("focal_distance", C.c_float), ("row_offset", C.c_int),
+                ("row_stride", C.c_int)]
+
+
+class CameraBasis(C.Structure):
+    _fields_ = [("E", C.c_float * 3), ("M", C.c_float * 3), ("H", C.c_float * 3), ("V", C.c_float * 3),
+                ("Cn", C.c_float * 3), ("Ah", C.c_float * 3), ("Bh", C.c_float * 3),
+                ("inv_wm1", C.c_float), ("inv_hm1", C.c_float), ("W", C.c_float), ("Hres", C.c_float)]
+
+
+_lib = None
+
+
+def build_oracle():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR, "libpt_oracle.so"], check=True)
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = os.path.join(ORACLE_DIR, "libpt_oracle.so")
+    if not os.path.exists(path):
+        build_oracle()
+    L = C.CDLL(path)
+    f3 = C.POINTER(C.c_float)
+    L.orc_hash.restype = C.c_uint32; L.orc_hash.argtypes = [C.c_uint32]
+    L.orc_lcg_seed.restype = C.c_uint32; L.orc_lcg_seed.argtypes = [C.c_uint32]
+    L.orc_lcg_next.restype = C.c_uint32; L.orc_lcg_next.argtypes = [C.c_uint32]
+    L.orc_u01.restype = C.c_float; L.orc_u01.argtypes = [C.c_uint32]
+    L.orc_stream_seed.restype = C.c_uint32; L.orc_stream_seed.argtypes = [C.c_uint32] * 3
+    L.orc_rng_from_thread.restype = None
+    L.orc_rng_from_thread.argtypes = [C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, f3]
+    L.orc_sincos.restype = None; L.orc_sincos.argtypes = [C.c_float, f3, f3]
+    L.orc_camera_setup.restype = None; L.orc_camera_setup.argtypes = [C.POINTER(Camera), C.POINTER(CameraBasis)]
+    L.orc_camera_ray.restype = None
+    L.orc_camera_ray.argtypes = [C.POINTER(CameraBasis), C.POINTER(Config), C.c_int, C.c_int,
+                                 C.c_float, C.c_float, C.c_float, C.c_float, f3, f3]
+    L.orc_sphere_test.restype = C.c_float; L.orc_sphere_test.argtypes = [C.POINTER(Geom), f3, f3, f3, f3]
+    L.orc_sphere_test_intminmax.restype = C.c_float; L.orc_sphere_test_intminmax.argtypes = [C.POINTER(Geom), f3, f3, f3, f3]
+    L.orc_box_test.restype = C.c_float; L.orc_box_test.argtypes = [C.POINTER(Geom), C.c_int, f3, f3, f3, f3]
+    L.orc_nearest_hit.restype = C.c_int
+    L.orc_nearest_hit.argtypes = [C.POINTER(Geom), C.c_int, C.POINTER(Material), f3, f3, f3, f3, f3]
+    L.orc_hemisphere.restype = None; L.orc_hemisphere.argtypes = [f3, C.c_float, C.c_float, f3]
+    L.orc_reflection_direction.restype = None; L.orc_reflection_direction.argtypes = [f3, f3, f3]
+    L.orc_transmission_direction.restype = C.c_int
+    L.orc_transmission_direction.argtypes = [f3, f3, C.c_float, C.c_float, f3]
+    L.orc_fresnel.restype = None; L.orc_fresnel.argtypes = [f3, f3, C.c_float, C.c_float, f3, f3]
+    L.orc_scatter.restype = C.c_int
+    L.orc_scatter.argtypes = [C.POINTER(Material), f3, f3, C.c_float, C.c_float, C.c_float, f3, f3, f3, f3]
+    L.orc_build_transform.restype = C.c_int; L.orc_build_transform.argtypes = [f3, f3, f3, f3, f3]
+    L.orc_display_pixel.restype = None; L.orc_display_pixel.argtypes = [f3, C.POINTER(C.c_uint8)]
+    L.orc_image_to_u8.restype = None
+    L.orc_image_to_u8.argtypes = [f3, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_uint8)]
+    L.orc_raycast_flat.restype = C.c_int
+    L.orc_raycast_flat.argtypes = [C.POINTER(Geom), C.c_int, C.POINTER(Material), C.c_int, C.POINTER(Camera),
+                                   f3, C.POINTER(C.c_int), C.c_int]
+    L.orc_render.restype = C.c_int
+    L.orc_render.argtypes = [C.POINTER(Geom), C.c_int, C.POINTER(Material), C.c_int, C.POINTER(Camera),
+                             C.POINTER(Config), C.c_int, C.c_int, f3, C.POINTER(C.c_uint64), C.c_int]
+    L.orc_trace_pool.restype = C.c_int
+    L.orc_trace_pool.argtypes = [C.POINTER(Geom), C.c_int, C.POINTER(Material), C.c_int, C.POINTER(Camera),
+                                 C.POINTER(Config), C.c_int, C.c_int] + [f3] * 9 + [C.POINTER(C.c_uint32)]
+    L.orc_max_threads.restype = C.c_int
+    _lib = L
+    return L
+
+
+def f32_from_bits(u):
+    return struct.unpack("<f", struct.pack("<I", u & 0xFFFFFFFF))[0]
+
+
+def bits_from_f32(f):
+    return struct.unpack("<I", struct.pack("<f", f))[0]
+
+
+def fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def vec3(*v):
+    return (C.c_float * 3)(*v)
+
+
+class Scene:
+    """Flattened scene for one frame: what cudaRaytraceCore builds at raytraceKernel.cu:179-206."""
+
+    def __init__(self, geoms, materials, camera, iterations=1, image_name=""):
+        self.geoms, self.materials, self.camera = geoms, materials, camera
+        self.iterations, self.image_name = iterations, image_name
+
+    @property
+    def G(self):
+        return len(self.geoms)
+
+    @property
+    def M(self):
+        return len(self.materials)
+
+    @property
+    def W(self):
+        return int(self.camera.resolution[0])
+
+    @property
+    def H(self):
+        return int(self.camera.resolution[1])
+
+    def geom_array(self):
+        return (Geom * self.G)(*self.geoms)
+
+    def material_array(self):
+        return (Material * self.M)(*self.materials)
+
+    def with_resolution(self, W, H):
+        """Same scene at another resolution, fov recomputed the way scene.cpp:201-205 does."""
+        import math
+        cam = Camera()
+        C.memmove(C.byref(cam), C.byref(self.camera), C.sizeof(Camera))
+        cam.resolution[0], cam.resolution[1] = float(W), float(H)
+        fovy = np.float32(self.camera.fov[1])
+        pi = np.float32(3.1415926535897932384626422832795028841971)
+        yscaled = np.float32(math.tan(float(np.float32(fovy * np.float32(pi / np.float32(180))))))
+        xscaled = np.float32(np.float32(yscaled * np.float32(W)) / np.float32(H))
+        fovx = np.float32(np.float32(np.float32(math.atan(float(xscaled))) * np.float32(180)) / pi)
+        cam.fov[0], cam.fov[1] = float(fovx), float(fovy)
+        return Scene(self.geoms, self.materials, cam, self.iterations, self.image_name)
+
+
+def load_golden_scene(name, frame=0):
+    """Scene PODs from a tests/golden/ref_scene_<name>.json dump (produced by the REFERENCE's
+    parser, oracle/gen_golden.py)."""
+    d = json.load(open(os.path.join(GOLD, "ref_scene_%s.json" % name)))
+    mats = []
+    for m in d["materials"]:
+        mm = Material()
+        C.memmove(C.byref(mm), struct.pack("<16I", *m), 64)
+        mats.append(mm)
+    geoms = []
+    for o in d["objects"]:
+        g = Geom()
+        g.type, g.materialid = o["type"], o["materialid"]
+        fr = o["frames"][frame]
+        for k in range(16):
+            g.transform[k] = f32_from_bits(fr["transform"][k])
+            g.inverseTransform[k] = f32_from_bits(fr["inverseTransform"][k])
+        geoms.append(g)
+    c = d["camera"]
+    cam = Camera()
+    cam.resolution[0], cam.resolution[1] = (f32_from_bits(v) for v in c["resolution"])
+    for k in range(3):
+        cam.position[k] = f32_from_bits(c["positions"][frame][k])
+        cam.view[k] = f32_from_bits(c["views"][frame][k])
+        cam.up[k] = f32_from_bits(c["ups"][frame][k])
+    cam.fov[0], cam.fov[1] = (f32_from_bits(v) for v in c["fov"])
+    return Scene(geoms, mats, cam, c["iterations"], c["imageName"])
+
+
+def default_config(depth=8, **kw):
+    cfg = Config(max_depth=depth, camera_mode=0, antialias=0, aperture=0.0, focal_distance=0.0,
+                 row_offset=0, row_stride=1)
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def render(scene, cfg, first=1, count=1, image=None, nthreads=0):
+    """Oracle render: returns (image float32 [H,W,3] holding the SUM, live counts uint64[depth+1])."""
+    L = lib()
+    if image is None:
+        image = np.zeros((scene.H, scene.W, 3), np.float32)
+    live = np.zeros(cfg.max_depth + 1, np.uint64)
+    rc = L.orc_render(scene.geom_array(), scene.G, scene.material_array(), scene.M, C.byref(scene.camera),
+                      C.byref(cfg), first, count, fptr(image), live.ctypes.data_as(C.POINTER(C.c_uint64)), nthreads)
+    assert rc == 0
+    return image, live
+
+
+def raycast_flat(scene, image=None, nthreads=0):
+    L = lib()
+    if image is None:
+        image = np.zeros((scene.H, scene.W, 3), np.float32)
+    hit = np.zeros((scene.H, scene.W), np.int32)
+    rc = L.orc_raycast_flat(scene.geom_array(), scene.G, scene.material_array(), scene.M, C.byref(scene.camera),
+                            fptr(image), hit.ctypes.data_as(C.POINTER(C.c_int)), nthreads)
+    assert rc == 0
+    return image, hit
+
+
+def trace_pool(scene, cfg, iteration, bounces):
+    L = lib()
+    n = scene.W * scene.H
+    arrs = [np.zeros(n, np.float32) for _ in range(9)]
+    pix = np.zeros(n, np.uint32)
+    cnt = L.orc_trace_pool(scene.geom_array(), scene.G, scene.material_array(), scene.M, C.byref(scene.camera),
+                           C.byref(cfg), iteration, bounces, *[fptr(a) for a in arrs],
+                           pix.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return cnt, [a[:cnt] for a in arrs], pix[:cnt]
