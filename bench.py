@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- Mray/s of the MI355X path tracer on BASELINE.json's headline configuration.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+A "step" is ONE render iteration of the workload: one camera ray per pixel of the frame traced
+for `depth` bounces through generate -> (trace + scatter + accumulate + compact)* on the GPU(s).
+Workload at every N (BASELINE configs[2], the configuration the metric is quoted on):
+scenes/cornell_mirror.txt = Cornell box, 1920x1080, 8 bounces, diffuse + perfect specular, stream
+compaction on.  Inputs (scene tables, accumulator) are resident in HBM before the timed region.
+
+Multi-GPU: the frame's rows are interleaved over the ranks (row y -> rank y % N); each rank keeps
+a full-frame accumulator (zeros outside its rows) and ONE RCCL reduce(sum) to rank 0 ends the
+timed region -> "scaling": "strong" (total work fixed).
+
+metric value = W*H*steps*depth / seconds / 1e6  ("rays launched x bounces / s", BASELINE.json).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+RAY_BYTES = 40                 # SoA ray record: o(12) d(12) throughput(12) pixel(4)
+ACCUM_BYTES = 24               # fp32 RGB accumulator read + write for a path that ends on an emitter
+
+WORKLOADS = {
+    "c3": ("scenes/cornell_mirror.txt", 8, "configs[2]: Cornell box 1920x1080, 8 bounces, diffuse + perfect specular, compaction on"),
+    "c2": ("scenes/cornell.txt", 8, "configs[1]: sampleScene-equivalent Cornell box 800x800, 8 bounces, diffuse only"),
+    "c4": ("scenes/random256.txt", 8, "configs[3]: 1920x1080, 8 bounces, 256 random spheres+cubes"),
+}
+
+
+def reduce_to_root(tensor, dst=0):
+    """Sum the per-rank accumulators on rank `dst` (RCCL over xGMI when backend is nccl).
+    Adding zeros is exact, so the row-sharded sum is bit-identical to a single-GPU render."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.reduce(tensor, dst=dst, op=dist.ReduceOp.SUM)
+    return tensor
+
+
+def algorithmic_bytes(stats, depth):
+    """HBM bytes the trace+scatter+compact launches have to move: every ray
+    entering bounce k is read once (40 B), every survivor of bounces 0..D-2 is written once
+    compacted (40 B; the last bounce writes nothing back), every path that ends on an emitter
+    reads+writes its accumulator pixel (24 B).  Geometry/material tables are LDS/L2 traffic = 0."""
+    live = [int(stats.live[k]) for k in range(depth + 1)]
+    read = sum(live[k] for k in range(depth)) * RAY_BYTES
+    written = sum(live[k] for k in range(1, depth)) * RAY_BYTES
+    return read + written + int(stats.emitted) * ACCUM_BYTES, live
+
+
+def cpu_baseline(scene_path, depth, budget_s=15.0):
+    """The CPU oracle (oracle/pt_oracle.c, "port") timed on this host's cores on a bounded sample of
+    the same workload: whole-frame iterations of the same scene/depth until ~budget_s is used."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+    import numpy as np
+    import orc
+    pkg = importlib.import_module("project2-pathtracer_amd")
+    sf = pkg.SceneFile(os.path.join(ROOT, scene_path))
+    geoms, mats, cam = sf.flatten(0)
+    og = (orc.Geom * len(geoms))()
+    for i, g in enumerate(geoms):
+        og[i].type, og[i].materialid = g.type, g.materialid
+        for r in range(3):
+            for c in range(4):
+                og[i].transform[4 * r + c] = g.transform[4 * r + c]
+                og[i].inverseTransform[4 * r + c] = g.inverseTransform[4 * r + c]
+        og[i].transform[15] = og[i].inverseTransform[15] = 1.0
+    om = (orc.Material * len(mats))()
+    C.memmove(om, mats, C.sizeof(om))
+    oc = orc.Camera()
+    C.memmove(C.byref(oc), C.byref(cam), 52)
+    W, H = int(cam.resolution[0]), int(cam.resolution[1])
+    L = orc.lib()
+    cores = L.orc_max_threads()
+    cfg = orc.default_config(depth)
+    img = np.zeros((H, W, 3), np.float32)
+    live = np.zeros(depth + 1, np.uint64)
+
+    def run(first, count):
+        t0 = time.perf_counter()
+        rc = L.orc_render(og, len(og), om, len(om), C.byref(oc), C.byref(cfg), first, count, orc.fptr(img),
+                          live.ctypes.data_as(C.POINTER(C.c_uint64)), cores)
+        assert rc == 0
+        return time.perf_counter() - t0
+
+    t1 = run(1, 1)
+    n = max(1, min(64, int(budget_s / max(t1, 1e-3)) - 1))
+    t = run(2, n)
+    return {"value": round(W * H * n * depth / t / 1e6, 3), "unit": "Mray/s", "cores": int(cores), "kind": "port",
+            "sample": "%d whole-frame iterations of the same workload (%dx%d, %d bounces) with oracle/pt_oracle.c, OpenMP over rows, %.1f s"
+                      % (n, W, H, depth, t)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events in the timed region")
+    ap.add_argument("--geometry-path", type=int, default=0)
+    ap.add_argument("--chunk-rays", type=int, default=0)
+    ap.add_argument("--blocks-per-cu", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the path tracer has no CPU fallback")
+    backend = os.environ.get("PT_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    device = local_rank % ndev
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+
+    pkg = importlib.import_module("project2-pathtracer_amd")
+    scene_path, depth, desc = WORKLOADS[args.workload]
+    sf = pkg.SceneFile(os.path.join(ROOT, scene_path))
+    geoms, mats, cam = sf.flatten(0)
+    W, H = int(cam.resolution[0]), int(cam.resolution[1])
+
+    tracer = pkg.PathTracer(pkg.default_config(device=device, max_depth=depth, row_offset=rank, row_stride=world,
+                                               geometry_path=args.geometry_path, chunk_rays=args.chunk_rays,
+                                               blocks_per_cu=args.blocks_per_cu))
+    tracer.upload(geoms, mats, cam)
+    accum = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda:%d" % device)
+    tracer.bind_device_image(accum)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    # warm-up (untimed)
+    tracer.render(1, args.warmup)
+    tracer.sync()
+    if world > 1 and backend == "nccl":
+        reduce_to_root(accum.clone())          # RCCL communicator setup outside the timed region
+    torch.cuda.synchronize()
+    accum.zero_()
+    tracer.reset_stats()
+    tracer.set_profiling(not args.no_kernel_events)
+
+    # timed region: exactly K steps + the frame reduce
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tracer.render(args.warmup + 1, args.steps)
+    tracer.sync()
+    if world > 1:
+        if backend == "nccl":
+            reduce_to_root(accum)
+        else:                                   # CPU rehearsal of the N>1 path (gloo)
+            host = accum.cpu()
+            reduce_to_root(host)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda:%d" % device if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    stats = tracer.stats()
+    nbytes, live = algorithmic_bytes(stats, depth)
+    result = None
+    if rank == 0:
+        value = W * H * args.steps * depth / elapsed / 1e6
+        roof = None
+        if stats.bounce_ms > 0 and stats.bounce_launches:
+            launches = int(stats.bounce_launches)
+            avg_ms = stats.bounce_ms / launches
+            achieved = nbytes / (stats.bounce_ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get(args.workload, {}).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roof = {"bound": "hbm", "kernel": "k_bounce (trace + scatter + accumulate + stable compaction)",
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": round(nbytes / launches), "avg_launch_us": round(avg_ms * 1e3, 2),
+                    "launches": launches, "rank0_share_of_frame": round(1.0 / world, 4)}
+        result = {
+            "metric": "Mray/s (rays launched x bounces / s) at 1080p, 8 bounces" if args.workload != "c2" else "Mray/s (rays launched x bounces / s)",
+            "value": round(value, 1), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "scene": scene_path, "resolution": [W, H], "bounces": depth,
+                       "rays_per_step": W * H, "sharding": "rows interleaved over %d GPU(s), 1 RCCL reduce per frame" % world,
+                       "live_ray_bounces_per_step": round(sum(live[:depth]) / max(1, int(stats.iterations))),
+                       "kernel_events_in_timed_region": not args.no_kernel_events},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(scene_path, depth)
+        print(json.dumps(result), flush=True)
+    tracer.close()
+    if world > 1:
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()

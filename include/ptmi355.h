@@ -1,0 +1,193 @@
+/*
+ * ptmi355.h -- C ABI of libptmi355.so, the MI355X-native (gfx950 / HIP) replacement for the
+ * per-iteration render path of CIS565 Project2-Pathtracer.
+ *
+ * The reference's host code reaches this path through ONE C++ symbol,
+ *     void cudaRaytraceCore(uchar4*, camera*, int frame, int iterations,
+ *                           material*, int, geom*, int);
+ * (declared /root/reference/src/raytraceKernel.h:18, defined src/raytraceKernel.cu:164-227,
+ * called src/main.cpp:126).  The adaptor TU project2-pathtracer_amd/adaptor/cuda_raytrace_core.cpp
+ * defines exactly that symbol and forwards to the functions below; nothing in this header
+ * mentions a C++ or a torch type: plain pointers, sizes and POD structs only.
+ *
+ * Every function returns 0 on success and a negative pt_status otherwise; pt_last_error()
+ * returns the message.  The reference's convention (print "Cuda error: ..." and
+ * exit(EXIT_FAILURE), src/raytraceKernel.cu:20-26) is applied by the adaptor, not here.
+ *
+ * There is NO CPU fallback: pt_create fails with PT_ERR_NO_DEVICE when no gfx950 device is
+ * visible, and every render entry point needs a context.
+ */
+#ifndef PTMI355_H
+#define PTMI355_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTMI355_ABI_VERSION 1
+
+typedef enum {
+    PT_OK = 0,
+    PT_ERR_NO_DEVICE = -1,      /* no HIP device / not gfx950 */
+    PT_ERR_HIP = -2,            /* a HIP runtime call failed (message has the call) */
+    PT_ERR_ARGUMENT = -3,
+    PT_ERR_STATE = -4,          /* e.g. render before pt_upload_scene */
+    PT_ERR_PARSE = -5,          /* scene file */
+    PT_ERR_IO = -6
+} pt_status;
+
+/* == `material`, /root/reference/src/sceneStructs.h:62-73 (64 bytes, same field order) */
+typedef struct {
+    float color[3];
+    float specularExponent;
+    float specularColor[3];
+    float hasReflective;
+    float hasRefractive;
+    float indexOfRefraction;
+    float hasScatter;
+    float absorptionCoefficient[3];
+    float reducedScatterCoefficient;
+    float emittance;
+} pt_material;
+
+/* The part of `staticGeom` (src/sceneStructs.h:32-40) the kernels read, per frame: type
+ * (GEOMTYPE: 0 SPHERE, 1 CUBE, 2 MESH -- src/sceneStructs.h:14), materialid, and rows x,y,z
+ * of transform / inverseTransform (cudaMat4 rows, src/cudaMat4.h:18-23; the w row is
+ * (0,0,0,1) for every matrix scene.cpp builds and multiplyMV never reads it,
+ * src/intersections.h:53-59).  104 bytes. */
+typedef struct {
+    int   type;
+    int   materialid;
+    float transform[12];
+    float inverseTransform[12];
+} pt_geom;
+
+/* == `cameraData`, src/sceneStructs.h:42-48 (52 bytes); fov = half-angles in degrees */
+typedef struct {
+    float resolution[2];
+    float position[3];
+    float view[3];
+    float up[3];
+    float fov[2];
+} pt_camera;
+
+/* Render options the reference hard-codes or lacks (traceDepth src/raytraceKernel.cu:166;
+ * README.md:47-51,63).  Zero-initialise, then pt_config_default(). */
+typedef struct {
+    int   device;            /* HIP device ordinal */
+    int   mode;              /* 0 = path trace (generate -> bounce* -> accumulate)
+                                1 = the reference kernel as shipped: one hit, flat material
+                                    colour OVERWRITES the pixel (src/raytraceKernel.cu:123-159) */
+    int   max_depth;         /* bounces per path, 1..64 (mode 0) */
+    int   camera_mode;       /* 0 = reference ray incl. normalize(R) (raytraceKernel.cu:67-69)
+                                1 = corrected pinhole / thin lens */
+    int   antialias;         /* jitter pixel position by U(-.5,.5)^2 */
+    float aperture;          /* thin-lens radius, camera_mode 1; 0 = pinhole */
+    float focal_distance;
+    int   row_offset;        /* multi-GPU: this context owns rows y with y % row_stride == */
+    int   row_stride;        /*   row_offset (single GPU: 0, 1) */
+    int   geometry_path;     /* 0 = LDS-staged geometry table (default), 1 = scalar loads */
+    int   chunk_rays;        /* rays per compaction ticket (0 = default) */
+    int   blocks_per_cu;     /* persistent grid size = CUs * this (0 = default) */
+    int   profile;           /* 1 = bracket every kernel launch with HIP events */
+    int   reserved[7];
+} pt_config;
+
+typedef struct pt_context pt_context;
+
+/* per-kernel timing collected when cfg.profile = 1 (HIP events on the render stream) */
+typedef struct {
+    double generate_ms;      /* sums over the launches since pt_reset_stats */
+    double bounce_ms;        /* all trace+scatter+compact launches */
+    double display_ms;
+    uint64_t generate_launches;
+    uint64_t bounce_launches;
+    uint64_t display_launches;
+    uint64_t iterations;
+    uint64_t live[65];       /* live[k] = rays entering bounce k, summed over iterations;
+                                live[max_depth] = paths alive when the depth ran out */
+    uint64_t emitted;        /* paths that ended on an emitter (accumulator read+write) */
+} pt_stats;
+
+int         pt_abi_version(void);
+const char *pt_last_error(void);
+void        pt_config_default(pt_config *cfg);
+int         pt_device_count(void);               /* HIP devices visible (0 without a GPU) */
+
+int  pt_create(const pt_config *cfg, pt_context **out);
+void pt_destroy(pt_context *ctx);
+
+/* Scene for one frame == the packing cudaRaytraceCore does at src/raytraceKernel.cu:179-206.
+ * Copies; the caller keeps ownership.  (Re)allocates the ray pool for the resolution. */
+int  pt_upload_scene(pt_context *ctx, const pt_geom *geoms, int ngeoms,
+                     const pt_material *materials, int nmaterials, const pt_camera *camera);
+
+/* Accumulator = camera::image (glm::vec3[W*H], index x+y*W, y=0 top; src/raytraceKernel.cu:176).
+ * host_rgb == NULL zeroes it.  */
+int  pt_set_image(pt_context *ctx, const float *host_rgb);
+/* Render into a caller-owned DEVICE buffer of W*H*3 floats instead (e.g. a torch tensor that is
+ * later reduced with RCCL); NULL returns to the internal buffer. */
+int  pt_bind_device_image(pt_context *ctx, void *device_rgb);
+int  pt_get_image(pt_context *ctx, float *host_rgb);       /* synchronises; the SUM over iterations */
+
+/* Enqueue iterations [first, first+count) (1-based like main.cpp:110) on the context's stream;
+ * asynchronous.  Each adds one path per owned pixel into the accumulator. */
+int  pt_render(pt_context *ctx, int first_iteration, int count);
+int  pt_sync(pt_context *ctx);
+
+/* sendImageToPBO (src/raytraceKernel.cu:88-119): (accumulator*scale)*255, clamp above only,
+ * truncate, {x=r,y=g,z=b,w=0}.  scale = 1 is the reference.  out may be host or device memory
+ * (W*H*4 bytes); NULL is ignored.  Synchronises when out is host memory. */
+int  pt_display(pt_context *ctx, float scale, void *out_xyzw, int out_is_device);
+
+/* switch the per-launch HIP-event bracketing on or off (same as cfg.profile) */
+int  pt_set_profiling(pt_context *ctx, int enabled);
+int  pt_get_stats(pt_context *ctx, pt_stats *out);          /* synchronises */
+int  pt_reset_stats(pt_context *ctx);
+int  pt_get_resolution(pt_context *ctx, int *w, int *h, int *owned_pixels);
+
+/* ---- parity hooks (used by tests; cheap, not on the render path) ------------------- */
+
+/* Primary ray + nearest hit for every pixel of the frame (the body of raytraceRay without the
+ * colour write): dir[W*H*3], hit[W*H] (-1 = miss), t[W*H], P[W*H*3], N[W*H*3]; any may be NULL. */
+int  pt_debug_primary_hits(pt_context *ctx, float *dir, int *hit, float *t, float *P, float *N);
+/* Ray pool after `bounces` bounces of one iteration, compacted in generation order.  Arrays of
+ * capacity owned_pixels (any may be NULL); *count receives the number of live rays. */
+int  pt_debug_trace_pool(pt_context *ctx, int iteration, int bounces, int *count,
+                         float *ox, float *oy, float *oz, float *dx, float *dy, float *dz,
+                         float *tr, float *tg, float *tb, uint32_t *pixel);
+/* generateRandomNumberFromThread (src/raytraceKernel.cu:30-37) evaluated on the device for n
+ * (x,y) pairs. */
+int  pt_debug_rng_from_thread(pt_context *ctx, float resx, float resy, float time, int n,
+                              const int *xy, float *out3);
+/* device evaluations of the scatter primitives for n inputs (interactions.h signatures) */
+int  pt_debug_hemisphere(pt_context *ctx, int n, const float *normal3, const float *xi2, float *out3);
+int  pt_debug_sincos(pt_context *ctx, int n, const float *a, float *s, float *c);
+
+/* ---- host-side scene I/O (no GPU needed; src/scene.cpp grammar, src/image.cpp output) ---- */
+
+typedef struct pt_scene pt_scene;
+
+int  pt_scene_load(const char *path, pt_scene **out);       /* PT_ERR_IO / PT_ERR_PARSE */
+void pt_scene_free(pt_scene *s);
+int  pt_scene_counts(const pt_scene *s, int *ngeoms, int *nmaterials, int *nframes, int *iterations);
+const char *pt_scene_image_name(const pt_scene *s);
+/* flatten frame `frame` the way cudaRaytraceCore does; arrays sized by pt_scene_counts */
+int  pt_scene_flatten(const pt_scene *s, int frame, pt_geom *geoms, pt_material *materials, pt_camera *camera);
+/* full 4x4 rows of transform / inverse of object i at frame f (parity with scene.cpp:123-125) */
+int  pt_scene_object_matrices(const pt_scene *s, int object, int frame, float transform16[16], float inverse16[16]);
+/* buildTransformationMatrix + inverse (src/utilities.cpp:70-86) */
+int  pt_build_transform(const float t[3], const float r[3], const float s[3], float transform16[16], float inverse16[16]);
+
+/* gamma + clamp + u8 exactly as image::saveImageRGB (src/image.cpp:40-87) with the settings of
+ * main.cpp:143-147; out_rgb holds W*H*3 bytes, top row first. */
+int  pt_image_to_u8(const float *rgb_sum, int w, int h, int divisor, float gamma, uint8_t *out_rgb);
+/* writes .bmp (24-bit, bottom-up, like stbi_write_bmp) or .png by extension */
+int  pt_image_save(const char *path, const float *rgb_sum, int w, int h, int divisor, float gamma);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTMI355_H */

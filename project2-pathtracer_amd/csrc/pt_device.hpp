@@ -1,0 +1,324 @@
+// pt_device.hpp -- device-side primitives of the gfx950 path tracer.
+//
+// Each function states the reference function whose result it reproduces (paths relative to
+// /root/reference).  Arithmetic contract: binary32, round-to-nearest-even,
+// no FMA contraction (this TU is compiled with -ffp-contract=off), correctly rounded
+// division and sqrt (hipcc default), sums associated left to right exactly as the
+// reference's C++ expressions are.  The expression trees are deliberately spelled out:
+// the CPU oracle must agree with these kernels bit for bit (up to the sign of zero).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pt_camrec.hpp"
+
+namespace ptd {
+
+// src/utilities.h:20-26
+#define PT_PI 3.1415926535897932384626422832795028841971f
+#define PT_TWO_PI 6.2831853071795864769252867665590057683943f
+#define PT_SQRT_OF_ONE_THIRD 0.5773502691896257645091487805019574556476f
+#define PT_EPSILON .000000001f
+#define PT_RAY_BIAS 0.0002f
+#define PT_TRANSMIT_BIAS 0.001f   // build-defined
+
+struct f3 { float x, y, z; };
+
+__device__ __forceinline__ f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ f3 operator*(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ f3 operator/(f3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ f3 neg(f3 a) { return mk(-a.x, -a.y, -a.z); }
+// glm::dot / cross / length / normalize (src/glm/core/func_geometric.inl:158-167,199-211,59-68,239-248)
+__device__ __forceinline__ float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ f3 cross(f3 x, f3 y) {
+    return mk(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y);
+}
+__device__ __forceinline__ float length(f3 a) { return __builtin_sqrtf(dot(a, a)); }
+__device__ __forceinline__ f3 normalize(f3 a) { return a * (1.0f / __builtin_sqrtf(dot(a, a))); }
+
+// ---------------------------------------------------------------- RNG ------------------
+// hash: src/intersections.h:26-34
+__device__ __forceinline__ uint32_t hash(uint32_t a) {
+    a = (a + 0x7ed55d16u) + (a << 12);
+    a = (a ^ 0xc761c23cu) ^ (a >> 19);
+    a = (a + 0x165667b1u) + (a << 5);
+    a = (a + 0xd3a2646cu) ^ (a << 9);
+    a = (a + 0xfd7046c5u) + (a << 3);
+    a = (a ^ 0xb55a4f09u) ^ (a >> 16);
+    return a;
+}
+// thrust::default_random_engine = minstd_rand (a = 48271, m = 2^31-1); m is a Mersenne prime so
+// x mod m folds as (x & m) + (x >> 31) with one conditional subtract (no 64-bit division).
+__device__ __forceinline__ uint32_t lcg_seed(uint32_t s) {
+    uint32_t r = (s & 0x7FFFFFFFu) + (s >> 31);
+    if (r >= 0x7FFFFFFFu) r -= 0x7FFFFFFFu;
+    return r == 0u ? 1u : r;
+}
+__device__ __forceinline__ uint32_t lcg_next(uint32_t x) {
+    uint64_t p = (uint64_t)x * 48271ull;
+    uint32_t r = (uint32_t)(p & 0x7FFFFFFFull) + (uint32_t)(p >> 31);
+    if (r >= 0x7FFFFFFFu) r -= 0x7FFFFFFFu;
+    return r;
+}
+// uniform_real_distribution<float>(0,1): float(x - 1) / 2^31
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x - 1u) / 2147483648.0f; }
+// build-defined stream seed
+__device__ __forceinline__ uint32_t stream_seed(uint32_t pixel, uint32_t iteration, uint32_t stream) {
+    return hash(hash(pixel) + 0x9E3779B9u * iteration + stream);
+}
+
+// sin/cos of a in [0, 2pi]: Cody-Waite by pi/2 + Cephes-coefficient polynomials, +,-,* only.
+__device__ __forceinline__ void sincos_poly(float a, float &s, float &c) {
+    int k = (int)((a * 0.636619772367581343f) + 0.5f);
+    float kf = (float)k;
+    float r = ((a - (kf * 1.5703125f)) - (kf * 4.837512969970703125e-4f)) - (kf * 7.54978995489188216e-8f);
+    float z = r * r;
+    float sp = (((((-1.9515295891e-4f * z) + 8.3321608736e-3f) * z) - 1.6666654611e-1f) * z) * r + r;
+    float cp = ((((((2.443315711809948e-5f * z) - 1.388731625493765e-3f) * z) + 4.166664568298827e-2f) * z) * z
+                - (0.5f * z)) + 1.0f;
+    int q = k & 3;
+    float s0 = (q & 1) ? cp : sp;
+    float c0 = (q & 1) ? sp : cp;
+    s = (q & 2) ? -s0 : s0;
+    c = (q == 1 || q == 2) ? -c0 : c0;
+}
+
+// ---------------------------------------------------------------- tables ---------------
+// One primitive as the kernels read it: rows x,y,z of inverseTransform and transform
+// (multiplyMV never reads row w, src/intersections.h:53-59), 28 dwords = 112 B so that every
+// row is a 16-byte LDS read.
+struct GeomRec {
+    float inv[12];
+    float xf[12];
+    int type;
+    int mat;
+    int inside_hits;   // box only: material is refractive (build extension)
+    int pad;
+};
+// material fields the scatter reads (src/sceneStructs.h:62-73), 12 dwords
+struct MatRec {
+    float color[3];
+    float emittance;
+    float spec[3];
+    float refl;
+    float refr;
+    float ior;
+    float pad[2];
+};
+
+// multiplyMV with w = 1 (src/intersections.h:53-59): ((m0*x + m1*y) + m2*z) + m3*1
+__device__ __forceinline__ f3 mul_point(const float *m, f3 v) {
+    return mk((((m[0] * v.x) + (m[1] * v.y)) + (m[2] * v.z)) + m[3],
+              (((m[4] * v.x) + (m[5] * v.y)) + (m[6] * v.z)) + m[7],
+              (((m[8] * v.x) + (m[9] * v.y)) + (m[10] * v.z)) + m[11]);
+}
+// multiplyMV with w = 0: the "+ m3*0" term only affects the sign of a zero result
+__device__ __forceinline__ f3 mul_vector(const float *m, f3 v) {
+    return mk(((m[0] * v.x) + (m[1] * v.y)) + (m[2] * v.z),
+              ((m[4] * v.x) + (m[5] * v.y)) + (m[6] * v.z),
+              ((m[8] * v.x) + (m[9] * v.y)) + (m[10] * v.z));
+}
+
+// sphereIntersectionTest (src/intersections.h:168-204) incl. getPointOnRay's second
+// normalize and its double-precision `t-.0001` (:46-48).  Returns world distance or -1.
+__device__ __forceinline__ float sphere_test(const float *inv, const float *xf, f3 o, f3 d, f3 &P, f3 &N) {
+    f3 ro = mul_point(inv, o);
+    f3 rd = normalize(mul_vector(inv, d));
+    float b = dot(ro, rd);
+    float radicand = b * b - (dot(ro, ro) - (0.5f * 0.5f));
+    if (radicand < 0.0f) return -1.0f;
+    float sq = __builtin_sqrtf(radicand);
+    float first = -b;
+    float t1 = first + sq;
+    float t2 = first - sq;
+    float t;
+    if (t1 < 0.0f && t2 < 0.0f) return -1.0f;
+    else if (t1 > 0.0f && t2 > 0.0f) t = fminf(t1, t2);
+    else t = fmaxf(t1, t2);
+    float tt = (float)((double)t - .0001);
+    f3 pobj = ro + normalize(rd) * tt;
+    f3 wp = mul_point(xf, pobj);
+    f3 centre = mk(xf[3], xf[7], xf[11]);          // multiplyMV(transform, (0,0,0,1))
+    P = wp;
+    N = normalize(wp - centre);
+    return length(o - wp);
+}
+
+// boxIntersectionTest on the unit cube (src/intersections.h:73-164); inside_hits is the
+// build's extension for refractive boxes (a ray starting inside leaves through tmax).
+__device__ __forceinline__ float box_test(const float *inv, const float *xf, int inside_hits, f3 o, f3 d,
+                                          f3 &P, f3 &N) {
+    f3 ro = mul_point(inv, o);
+    f3 p1 = mul_point(inv, o + d);
+    f3 rd = normalize(p1 - ro);
+    float ix = 1.0f / rd.x, iy = 1.0f / rd.y, iz = 1.0f / rd.z;
+    float tmin, tmax, tymin, tymax, tzmin, tzmax;
+    if (!(ix < 0.0f)) { tmin = (-.5f - ro.x) * ix; tmax = (.5f - ro.x) * ix; }
+    else              { tmin = (.5f - ro.x) * ix;  tmax = (-.5f - ro.x) * ix; }
+    if (!(iy < 0.0f)) { tymin = (-.5f - ro.y) * iy; tymax = (.5f - ro.y) * iy; }
+    else              { tymin = (.5f - ro.y) * iy;  tymax = (-.5f - ro.y) * iy; }
+    if ((tmin > tymax) || (tymin > tmax)) return -1.0f;
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    if (!(iz < 0.0f)) { tzmin = (-.5f - ro.z) * iz; tzmax = (.5f - ro.z) * iz; }
+    else              { tzmin = (.5f - ro.z) * iz;  tzmax = (-.5f - ro.z) * iz; }
+    if ((tmin > tzmax) || (tzmin > tmax)) return -1.0f;
+    if (tzmin > tmin) tmin = tzmin;
+    if (tzmax < tmax) tmax = tzmax;
+    float th = tmin;
+    if (tmin < 0.0f) {
+        if (!inside_hits || !(tmax > 0.0f)) return -1.0f;
+        th = tmax;
+    }
+    f3 os = ro + rd * th;
+    // face cascade +x,+y,+z,-x,-y,-z (:143-155); N = multiplyMV(transform,(n,0)) = +-column
+    int col = -1;
+    float sgn = 1.0f;
+    if (fabsf(os.x - .5f) < .001f) { col = 0; }
+    else if (fabsf(os.y - .5f) < .001f) { col = 1; }
+    else if (fabsf(os.z - .5f) < .001f) { col = 2; }
+    else if (fabsf(os.x + .5f) < .001f) { col = 0; sgn = -1.0f; }
+    else if (fabsf(os.y + .5f) < .001f) { col = 1; sgn = -1.0f; }
+    else if (fabsf(os.z + .5f) < .001f) { col = 2; sgn = -1.0f; }
+    f3 wp = mul_point(xf, os);
+    P = wp;
+    if (col < 0) N = mk(0.0f, 0.0f, 0.0f);
+    else N = mk(xf[col] * sgn, xf[4 + col] * sgn, xf[8 + col] * sgn);
+    return length(wp - o);
+}
+
+// ---------------------------------------------------------------- scatter --------------
+// calculateRandomDirectionInHemisphere (src/interactions.h:62-87)
+__device__ __forceinline__ f3 hemisphere(f3 normal, float xi1, float xi2) {
+    float up = __builtin_sqrtf(xi1);
+    float over = __builtin_sqrtf(1.0f - up * up);
+    float around = xi2 * PT_TWO_PI;
+    f3 dnn;
+    if (fabsf(normal.x) < PT_SQRT_OF_ONE_THIRD) dnn = mk(1.0f, 0.0f, 0.0f);
+    else if (fabsf(normal.y) < PT_SQRT_OF_ONE_THIRD) dnn = mk(0.0f, 1.0f, 0.0f);
+    else dnn = mk(0.0f, 0.0f, 1.0f);
+    f3 p1 = normalize(cross(normal, dnn));
+    f3 p2 = normalize(cross(normal, p1));
+    float sn, cs;
+    sincos_poly(around, sn, cs);
+    return ((normal * up) + (p1 * (cs * over))) + (p2 * (sn * over));
+}
+// calculateReflectionDirection (stub src/interactions.h:47-50)
+__device__ __forceinline__ f3 reflect_dir(f3 n, f3 i) {
+    float k = 2.0f * dot(n, i);
+    return i - n * k;
+}
+// calculateFresnel + calculateTransmissionDirection (stubs src/interactions.h:42-44,53-59)
+// evaluated together: returns the reflection coefficient (1 = total internal reflection) and
+// the transmitted direction.
+__device__ __forceinline__ float fresnel_transmit(f3 n, f3 i, float ior_i, float ior_t, f3 &tdir) {
+    float eta = ior_i / ior_t;
+    float c = -dot(n, i);
+    float k = 1.0f - ((eta * eta) * (1.0f - (c * c)));
+    if (k < 0.0f) { tdir = mk(0.0f, 0.0f, 0.0f); return 1.0f; }
+    float ct = __builtin_sqrtf(k);
+    float rs = ((ior_i * c) - (ior_t * ct)) / ((ior_i * c) + (ior_t * ct));
+    float rp = ((ior_i * ct) - (ior_t * c)) / ((ior_i * ct) + (ior_t * c));
+    float R = 0.5f * ((rs * rs) + (rp * rp));
+    float a = (eta * c) - ct;
+    tdir = (i * eta) + (n * a);
+    return R;
+}
+
+// The calculateBSDF contract (stub src/interactions.h:96-103; spec DESIGN.md section 3.5).
+// Returns 0 diffuse, 1 reflected, 2 transmitted, 3 ended on an emitter (L set), 4 degenerate.
+// (Single exit with value selects: keeps o/d/thr in registers instead of scratch.)
+__device__ __forceinline__ int scatter(const MatRec &m, f3 P, f3 N, float u_sel, float xi1, float xi2,
+                                       f3 &o, f3 &d, f3 &thr, f3 &L) {
+    int code;
+    f3 no = o, nd = d, nthr = thr, nL = mk(0.0f, 0.0f, 0.0f);
+    const float nn = dot(N, N);
+    if (m.emittance > 0.0f) {
+        const f3 e = mk(m.color[0], m.color[1], m.color[2]) * m.emittance;
+        nL = thr * e;
+        code = 3;
+    } else if (!(nn > 0.0f)) {
+        code = 4;
+    } else {
+        const f3 n = N * (1.0f / __builtin_sqrtf(nn));
+        const float cosi = dot(n, d);
+        const f3 nf = (cosi > 0.0f) ? neg(n) : n;
+        const f3 spec = mk(m.spec[0], m.spec[1], m.spec[2]);
+        if (m.refr > 0.0f) {
+            const float ior = (m.ior > 0.0f) ? m.ior : 1.0f;
+            const bool entering = !(cosi > 0.0f);
+            const float ior_i = entering ? 1.0f : ior, ior_t = entering ? ior : 1.0f;
+            f3 tdir;
+            const float R = fresnel_transmit(nf, d, ior_i, ior_t, tdir);
+            nthr = thr * spec;
+            const bool refl = u_sel < R;
+            const f3 rdir = reflect_dir(nf, d);
+            const f3 o_r = P + nf * PT_RAY_BIAS, o_t = P - nf * PT_TRANSMIT_BIAS;
+            nd = refl ? rdir : tdir;
+            no = refl ? o_r : o_t;
+            code = refl ? 1 : 2;
+        } else if (m.refl > 0.0f) {
+            nd = reflect_dir(nf, d);
+            nthr = thr * spec;
+            no = P + nf * PT_RAY_BIAS;
+            code = 1;
+        } else {
+            nd = hemisphere(nf, xi1, xi2);
+            nthr = thr * mk(m.color[0], m.color[1], m.color[2]);
+            no = P + nf * PT_RAY_BIAS;
+            code = 0;
+        }
+    }
+    o = no; d = nd; thr = nthr; L = nL;
+    return code;
+}
+
+// ---------------------------------------------------------------- camera ---------------
+// per-pixel half of raycastFromCameraKernel (src/raytraceKernel.cu:62-74)
+__device__ __forceinline__ void camera_ray(const CamRec &c, uint32_t pixel, uint32_t iteration, f3 &o, f3 &d) {
+    int x = (int)(pixel % (uint32_t)c.W), y = (int)(pixel / (uint32_t)c.W);
+    f3 E = mk(c.E[0], c.E[1], c.E[2]);
+    float fx = (float)x, fy = (float)y;
+    float lu = 0.0f, lv = 0.0f;
+    bool lens = (c.camera_mode == 1) && (c.aperture > 0.0f);
+    if (c.antialias || lens) {
+        uint32_t st = lcg_seed(stream_seed(pixel, iteration, 0u));
+        st = lcg_next(st); float jx = u01(st) - 0.5f;
+        st = lcg_next(st); float jy = u01(st) - 0.5f;
+        st = lcg_next(st); lu = u01(st);
+        st = lcg_next(st); lv = u01(st);
+        if (c.antialias) { fx = fx + jx; fy = fy + jy; }
+    }
+    float sx = fx / c.wm1;
+    float sy = fy / c.hm1;
+    f3 P = (mk(c.M[0], c.M[1], c.M[2]) + mk(c.H[0], c.H[1], c.H[2]) * ((2.0f * sx) - 1.0f))
+           + mk(c.V[0], c.V[1], c.V[2]) * ((2.0f * sy) - 1.0f);
+    f3 PmE = P - E;
+    f3 oo = E, dd;
+    if (c.camera_mode == 0) {
+        f3 R = E + (PmE * 200.0f) / length(PmE);
+        dd = normalize(R);                 // the reference normalises the POINT R (:67-69)
+    } else {
+        f3 dn = normalize(PmE);
+        dd = dn;
+        if (lens) {
+            f3 Cn = mk(c.Cn[0], c.Cn[1], c.Cn[2]), Ah = mk(c.Ah[0], c.Ah[1], c.Ah[2]), Bh = mk(c.Bh[0], c.Bh[1], c.Bh[2]);
+            float tf = c.focal / dot(dn, Cn);
+            f3 F = E + dn * tf;
+            float rr = c.aperture * __builtin_sqrtf(lu);
+            float sn, cs;
+            sincos_poly(lv * PT_TWO_PI, sn, cs);
+            f3 Eo = (E + Ah * (rr * cs)) + Bh * (rr * sn);
+            oo = Eo;
+            dd = normalize(F - Eo);
+        }
+    }
+    o = oo;
+    d = dd;
+}
+
+}  // namespace ptd

@@ -1,0 +1,882 @@
+// pt_kernels.hip -- gfx950 kernels + the device half of the C ABI (include/ptmi355.h).
+//
+// Replaces the body of cudaRaytraceCore (/root/reference/src/raytraceKernel.cu:164-227) and the
+// kernels it launches (raytraceRay :123-159, sendImageToPBO :88-119) with a wavefront design:
+//
+//   k_generate   camera rays -> SoA ray pool (40 B/ray), resets the per-iteration sync block
+//   k_bounce     persistent blocks pull 256*RPT-ray chunks by ticket; each wave traces its
+//                contiguous span against the LDS-staged (or scalar-loaded) geometry table,
+//                scatters, accumulates emitter hits into the image, compacts survivors into a
+//                wave-private LDS stage (ballot + mbcnt), and the block places them in the
+//                output pool through a decoupled look-back scan over 8-byte {state,value}
+//                granules -> STABLE (generation-order) compaction in one pass
+//   k_bounce_last  final bounce: emitters only, nothing written back
+//   k_flat       the reference kernel as shipped (one hit, flat colour overwrite)
+//   k_display    sendImageToPBO
+//
+// No CPU fallback lives here: every entry point needs a gfx950 device.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/ptmi355.h"
+#include "pt_device.hpp"
+#include "pt_host.hpp"
+
+using namespace ptd;
+
+namespace {
+
+constexpr int kBlock = 256;          // 4 waves
+constexpr int kWaves = kBlock / 64;
+constexpr int kFields = 10;          // ox oy oz dx dy dz tr tg tb pixel
+constexpr uint32_t kSpinLimit = 1u << 24;
+
+typedef unsigned long long u64;
+
+// look-back granule: high 32 bits = state (0 empty, 1 block aggregate, 2 inclusive prefix),
+// low 32 bits = value.  One naturally aligned 8-byte agent-scope store / load each.
+constexpr u64 kStateAgg = 1ull << 32;
+constexpr u64 kStatePrefix = 2ull << 32;
+
+struct SyncBlock {                   // device-resident, one per context
+    uint32_t counts[72];             // live rays entering bounce k of the CURRENT iteration
+    uint32_t tickets[72];            // chunk tickets per bounce
+    u64 totals[72];                  // counts folded over finished iterations
+    u64 emitted;                     // paths ended on an emitter
+    uint32_t error;                  // look-back spin limit hit
+    uint32_t pad;
+};
+
+struct GenArgs {
+    CamRec cam;
+    float *pool;                     // field f at pool + f*cap
+    uint32_t cap;
+    uint32_t n_own;                  // rays this context generates per iteration
+    uint32_t iteration;
+    SyncBlock *sync;
+    u64 *status;
+    uint32_t status_words;
+    int depth;
+};
+
+struct BounceArgs {
+    const float *in;
+    float *out;
+    uint32_t cap;
+    float *image;
+    int G, M;
+    SyncBlock *sync;
+    u64 *status;                     // this bounce's granules [max_chunks]
+    uint32_t rpt;                    // 64-ray groups per wave per chunk
+    int bounce;
+    uint32_t iteration;
+};
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// ------------------------------------------------------------------ nearest hit --------
+// geometry loop of raytraceRay (src/raytraceKernel.cu:134-153)
+template <typename GeomPtr>
+__device__ __forceinline__ int nearest_hit(GeomPtr geoms, int G, f3 o, f3 d, float &tbest, f3 &P, f3 &N) {
+    float maxd = 100000000000000000.0f;
+    int hit = -1;
+    for (int i = 0; i < G; ++i) {
+        f3 p, n;
+        float depth;
+        const int type = geoms[i].type;
+        if (type == 0) depth = sphere_test(geoms[i].inv, geoms[i].xf, o, d, p, n);
+        else if (type == 1) depth = box_test(geoms[i].inv, geoms[i].xf, geoms[i].inside_hits, o, d, p, n);
+        else continue;
+        if (depth < maxd && depth > -PT_EPSILON) { maxd = depth; hit = i; P = p; N = n; }
+    }
+    tbest = maxd;
+    return hit;
+}
+
+// Dynamic LDS layout (all scratch lives in the dynamic region so that its base stays 16-byte
+// aligned): [0,64) control words | material table | geometry table (LDS path) | ray stage.
+constexpr uint32_t kCtrlBytes = 64;
+
+__device__ __forceinline__ void stage_tables(char *smem_base, const GeomRec *geoms, int G, const MatRec *mats, int M,
+                                             bool geoms_in_lds, GeomRec *&lg, MatRec *&lm) {
+    char *smem = smem_base + kCtrlBytes;
+    uint32_t *dst = reinterpret_cast<uint32_t *>(smem);
+    lm = reinterpret_cast<MatRec *>(smem);
+    const uint32_t mwords = (uint32_t)M * (sizeof(MatRec) / 4);
+    const uint32_t *msrc = reinterpret_cast<const uint32_t *>(mats);
+    for (uint32_t i = threadIdx.x; i < mwords; i += blockDim.x) dst[i] = msrc[i];
+    lg = reinterpret_cast<GeomRec *>(smem + ((mwords * 4 + 15) & ~15u));
+    if (geoms_in_lds) {
+        uint32_t *gdst = reinterpret_cast<uint32_t *>(lg);
+        const uint32_t gwords = (uint32_t)G * (sizeof(GeomRec) / 4);
+        const uint32_t *gsrc = reinterpret_cast<const uint32_t *>(geoms);
+        for (uint32_t i = threadIdx.x; i < gwords; i += blockDim.x) gdst[i] = gsrc[i];
+    }
+    __syncthreads();
+}
+
+__host__ __device__ inline uint32_t tables_bytes(int G, int M, bool geoms_in_lds) {
+    uint32_t b = kCtrlBytes + (((uint32_t)M * sizeof(MatRec) + 15) & ~15u);
+    if (geoms_in_lds) b += (uint32_t)G * sizeof(GeomRec);
+    return (b + 15) & ~15u;
+}
+
+// ------------------------------------------------------------------ generate -----------
+__global__ __launch_bounds__(kBlock) void k_generate(GenArgs a) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    // reset the sync state of this iteration (visible to the bounce kernels at the kernel boundary)
+    if (gid < a.status_words) a.status[gid] = 0ull;
+    if (blockIdx.x == 0 && threadIdx.x < 72) {
+        const uint32_t k = threadIdx.x;
+        a.sync->totals[k] += a.sync->counts[k];          // fold the previous iteration (stats)
+        a.sync->counts[k] = (k == 0) ? a.n_own : 0u;
+        a.sync->tickets[k] = 0u;
+    }
+    if (gid >= a.n_own) return;
+    // row-interleaved ownership: local row lr -> global row lr*stride + offset
+    const uint32_t W = (uint32_t)a.cam.W;
+    const uint32_t lr = gid / W, x = gid - lr * W;
+    const uint32_t y = lr * (uint32_t)a.cam.row_stride + (uint32_t)a.cam.row_offset;
+    const uint32_t pixel = y * W + x;
+    f3 o, d;
+    camera_ray(a.cam, pixel, a.iteration, o, d);
+    float *p = a.pool + gid;
+    const size_t cap = a.cap;
+    p[0 * cap] = o.x; p[1 * cap] = o.y; p[2 * cap] = o.z;
+    p[3 * cap] = d.x; p[4 * cap] = d.y; p[5 * cap] = d.z;
+    p[6 * cap] = 1.0f; p[7 * cap] = 1.0f; p[8 * cap] = 1.0f;
+    reinterpret_cast<uint32_t *>(p)[9 * cap] = pixel;
+}
+
+// ------------------------------------------------------------------ bounce -------------
+// decoupled look-back over the chunk granules; one lane.  Returns the exclusive prefix.
+__device__ __forceinline__ uint32_t lookback(u64 *status, uint32_t chunk, uint32_t total, SyncBlock *sync) {
+    if (chunk == 0) {
+        __hip_atomic_store(&status[0], kStatePrefix | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 0u;
+    }
+    __hip_atomic_store(&status[chunk], kStateAgg | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t excl = 0u;
+    uint32_t j = chunk;
+    uint32_t spins = 0u;
+    while (j > 0u) {
+        const u64 s = __hip_atomic_load(&status[j - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t state = (uint32_t)(s >> 32);
+        if (state == 0u) {
+            if (++spins > kSpinLimit) { sync->error = 1u; break; }   // bounded: never hang the device
+            __builtin_amdgcn_s_sleep(2);
+            continue;
+        }
+        excl += (uint32_t)s;
+        if (state == 2u) break;
+        --j;
+    }
+    __hip_atomic_store(&status[chunk], kStatePrefix | (u64)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return excl;
+}
+
+template <bool GEOM_LDS, bool LAST>
+__global__ __launch_bounds__(kBlock) void k_bounce(BounceArgs a, const GeomRec *__restrict__ geoms,
+                                                   const MatRec *__restrict__ mats) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t *ctrl = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *s_chunk = ctrl;            // [2], alternating per chunk
+    uint32_t *s_excl = ctrl + 2;
+    uint32_t *s_wtot = ctrl + 4;         // [kWaves]
+
+    GeomRec *lg;
+    MatRec *lm;
+    stage_tables(smem, geoms, a.G, mats, a.M, GEOM_LDS, lg, lm);
+    const uint32_t tb = tables_bytes(a.G, a.M, GEOM_LDS);
+    const uint32_t rpt = a.rpt;
+    const uint32_t span = 64u * rpt;                      // rays per wave per chunk
+    const uint32_t chunk_rays = span * kWaves;
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    float *stage = reinterpret_cast<float *>(smem + tb) + (size_t)wave * span * kFields;   // wave-private
+
+    const uint32_t n_in = a.sync->counts[a.bounce];
+    const size_t cap = a.cap;
+    uint32_t emitted = 0u, survivors_last = 0u, parity = 0u;
+
+    for (;;) {
+        if (threadIdx.x == 0) s_chunk[parity] = atomicAdd(&a.sync->tickets[a.bounce], 1u);
+        __syncthreads();
+        const uint32_t chunk = s_chunk[parity];
+        parity ^= 1u;
+        const uint32_t base = chunk * chunk_rays;
+        if (base >= n_in) break;                          // uniform: every block ends here
+
+        uint32_t wtotal = 0u;
+        for (uint32_t sub = 0; sub < rpt; ++sub) {
+            const uint32_t idx = base + wave * span + sub * 64u + lane;
+            bool alive = false;
+            f3 o, d, thr;
+            uint32_t pixel = 0u;
+            if (idx < n_in) {
+                const float *p = a.in + idx;
+                o = mk(p[0 * cap], p[1 * cap], p[2 * cap]);
+                d = mk(p[3 * cap], p[4 * cap], p[5 * cap]);
+                thr = mk(p[6 * cap], p[7 * cap], p[8 * cap]);
+                pixel = reinterpret_cast<const uint32_t *>(p)[9 * cap];
+                float t;
+                f3 P, N;
+                int hit;
+                if (GEOM_LDS) hit = nearest_hit(lg, a.G, o, d, t, P, N);
+                else hit = nearest_hit(geoms, a.G, o, d, t, P, N);
+                if (hit >= 0) {
+                    const int mid = GEOM_LDS ? lg[hit].mat : geoms[hit].mat;
+                    const MatRec m = lm[mid];
+                    if (LAST && !(m.emittance > 0.0f)) {
+                        alive = true;                     // depth exhausted: alive, contributes 0
+                    } else {
+                        uint32_t st = lcg_seed(stream_seed(pixel, a.iteration, 1u + (uint32_t)a.bounce));
+                        st = lcg_next(st); const float u_sel = u01(st);
+                        st = lcg_next(st); const float xi1 = u01(st);
+                        st = lcg_next(st); const float xi2 = u01(st);
+                        f3 L = mk(0.0f, 0.0f, 0.0f);
+                        const int code = scatter(m, P, N, u_sel, xi1, xi2, o, d, thr, L);
+                        if (code == 3) {
+                            // exactly one live path per pixel per iteration: plain read-modify-write
+                            float *px = a.image + (size_t)pixel * 3;
+                            px[0] = px[0] + L.x; px[1] = px[1] + L.y; px[2] = px[2] + L.z;
+                            emitted++;
+                        }
+                        alive = (code <= 2);
+                    }
+                }
+            }
+            const u64 ballot = __ballot(alive);
+            if (LAST) {
+                survivors_last += (uint32_t)__popcll(ballot);
+            } else {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32),
+                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
+                if (alive) {
+                    float *q = stage + wtotal + rank;
+                    q[0 * span] = o.x; q[1 * span] = o.y; q[2 * span] = o.z;
+                    q[3 * span] = d.x; q[4 * span] = d.y; q[5 * span] = d.z;
+                    q[6 * span] = thr.x; q[7 * span] = thr.y; q[8 * span] = thr.z;
+                    q[9 * span] = __uint_as_float(pixel);
+                }
+                wtotal += (uint32_t)__popcll(ballot);
+            }
+        }
+        if (LAST) continue;                               // nothing is written back at the last bounce
+
+        if (lane == 0) s_wtot[wave] = wtotal;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t total = s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
+            const uint32_t excl = lookback(a.status, chunk, total, a.sync);
+            *s_excl = excl;
+            if (base + chunk_rays >= n_in) a.sync->counts[a.bounce + 1] = excl + total;   // last chunk
+        }
+        __syncthreads();
+        uint32_t off = *s_excl;
+        for (uint32_t w = 0; w < wave; ++w) off += s_wtot[w];
+        float *outp = a.out + off;
+        for (uint32_t j = lane; j < wtotal; j += 64u) {
+#pragma unroll
+            for (int f = 0; f < kFields; ++f) outp[(size_t)f * cap + j] = stage[f * span + j];
+        }
+    }
+
+    // per-block stats: one atomic each at exit
+    if (LAST) {                                           // survivors_last is wave-uniform (ballot counts)
+        if (lane == 0 && survivors_last) atomicAdd(&a.sync->counts[a.bounce + 1], survivors_last);
+    }
+    for (int s = 32; s > 0; s >>= 1) emitted += __shfl_down(emitted, s);
+    if (lane == 0 && emitted) atomicAdd(&a.sync->emitted, (u64)emitted);
+}
+
+// ------------------------------------------------------------------ flat (reference) ---
+struct FlatArgs {
+    CamRec cam;
+    float *image;
+    const GeomRec *geoms;
+    const MatRec *mats;
+    int G, M;
+    uint32_t n_own;
+    // optional debug outputs
+    float *dir, *t, *P, *N;
+    int *hit;
+    int write_image;
+};
+
+// raytraceRay as shipped (src/raytraceKernel.cu:123-159): nearest hit, flat material colour
+// OVERWRITES the pixel, misses leave it untouched.  Also the primary-hit parity hook.
+__global__ __launch_bounds__(kBlock) void k_flat(FlatArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    GeomRec *lg;
+    MatRec *lm;
+    stage_tables(smem, a.geoms, a.G, a.mats, a.M, true, lg, lm);
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= a.n_own) return;
+    const uint32_t W = (uint32_t)a.cam.W;
+    const uint32_t lr = gid / W, x = gid - lr * W;
+    const uint32_t pixel = (lr * (uint32_t)a.cam.row_stride + (uint32_t)a.cam.row_offset) * W + x;
+    f3 o, d, P = mk(0, 0, 0), N = mk(0, 0, 0);
+    CamRec c = a.cam;
+    c.camera_mode = 0; c.antialias = 0;
+    camera_ray(c, pixel, 1u, o, d);
+    float t;
+    const int hit = nearest_hit(lg, a.G, o, d, t, P, N);
+    if (a.write_image && hit >= 0) {
+        const MatRec m = lm[lg[hit].mat];
+        float *px = a.image + (size_t)pixel * 3;
+        px[0] = m.color[0]; px[1] = m.color[1]; px[2] = m.color[2];
+    }
+    if (a.hit) a.hit[pixel] = hit;
+    if (a.t) a.t[pixel] = t;
+    if (a.dir) { a.dir[3 * pixel] = d.x; a.dir[3 * pixel + 1] = d.y; a.dir[3 * pixel + 2] = d.z; }
+    if (a.P) { a.P[3 * pixel] = P.x; a.P[3 * pixel + 1] = P.y; a.P[3 * pixel + 2] = P.z; }
+    if (a.N) { a.N[3 * pixel] = N.x; a.N[3 * pixel + 1] = N.y; a.N[3 * pixel + 2] = N.z; }
+}
+
+// sendImageToPBO (src/raytraceKernel.cu:88-119); scale = 1 is the reference
+__global__ __launch_bounds__(kBlock) void k_display(const float *image, uchar4 *out, uint32_t n, float scale) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r = (image[3 * i] * scale) * 255.0f, g = (image[3 * i + 1] * scale) * 255.0f,
+          b = (image[3 * i + 2] * scale) * 255.0f;
+    if (r > 255.0f) r = 255.0f;
+    if (g > 255.0f) g = 255.0f;
+    if (b > 255.0f) b = 255.0f;
+    uchar4 v;
+    v.w = 0; v.x = (unsigned char)r; v.y = (unsigned char)g; v.z = (unsigned char)b;
+    out[i] = v;
+}
+
+// ------------------------------------------------------------------ KAT kernels --------
+// generateRandomNumberFromThread (src/raytraceKernel.cu:30-37)
+__global__ void k_rng_from_thread(float resx, float time, int n, const int *xy, float *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int x = xy[2 * i], y = xy[2 * i + 1];
+    const int index = (int)((float)x + ((float)y * resx));
+    const uint32_t s = (uint32_t)((float)index * time);
+    uint32_t st = lcg_seed(hash(s));
+    st = lcg_next(st); out[3 * i] = u01(st);
+    st = lcg_next(st); out[3 * i + 1] = u01(st);
+    st = lcg_next(st); out[3 * i + 2] = u01(st);
+}
+
+__global__ void k_hemisphere(int n, const float *nrm, const float *xi, float *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    f3 r = hemisphere(mk(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]), xi[2 * i], xi[2 * i + 1]);
+    out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+}
+
+__global__ void k_sincos(int n, const float *a, float *s, float *c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float sn, cs;
+    sincos_poly(a[i], sn, cs);
+    s[i] = sn; c[i] = cs;
+}
+
+}  // namespace
+
+// =========================================================================== host side ==
+
+struct pt_context {
+    pt_config cfg;
+    hipStream_t stream = nullptr;
+    int n_cu = 0;
+    int W = 0, H = 0;
+    uint32_t n_own = 0, cap = 0;
+    int G = 0, M = 0;
+    CamRec cam;
+    float *pool[2] = {nullptr, nullptr};
+    float *image_own = nullptr;
+    float *image = nullptr;          // bound or own
+    GeomRec *d_geoms = nullptr;
+    MatRec *d_mats = nullptr;
+    SyncBlock *d_sync = nullptr;
+    u64 *d_status = nullptr;
+    uint32_t max_chunks = 0, rpt = 3, status_words = 0;
+    uchar4 *d_display = nullptr;
+    uint32_t lds_bytes = 0;
+    int grid_bounce = 0;
+    bool geom_lds = true;
+    bool scene_ready = false;
+    bool counts_pending = false;
+    // profiling
+    struct Ev { hipEvent_t a, b; int kind; };
+    std::vector<Ev> pending;
+    std::vector<hipEvent_t> free_events;
+    double ms[3] = {0, 0, 0};
+    uint64_t launches[3] = {0, 0, 0};
+    uint64_t iterations = 0;
+};
+
+namespace {
+
+#define HIPCHK(call)                                                                      \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            pth::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return PT_ERR_HIP;                                                            \
+        }                                                                                 \
+    } while (0)
+
+hipEvent_t take_event(pt_context *c) {
+    if (!c->free_events.empty()) { hipEvent_t e = c->free_events.back(); c->free_events.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct Scoped {
+    pt_context *c; int kind; hipEvent_t a = nullptr, b = nullptr;
+    Scoped(pt_context *ctx, int k) : c(ctx), kind(k) {
+        if (c->cfg.profile) { a = take_event(c); b = take_event(c); (void)hipEventRecord(a, c->stream); }
+    }
+    ~Scoped() {
+        c->launches[kind]++;
+        if (c->cfg.profile) { (void)hipEventRecord(b, c->stream); c->pending.push_back({a, b, kind}); }
+    }
+};
+
+int resolve_events(pt_context *c) {
+    for (auto &e : c->pending) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
+        c->ms[e.kind] += ms;
+        c->free_events.push_back(e.a);
+        c->free_events.push_back(e.b);
+    }
+    c->pending.clear();
+    return PT_OK;
+}
+
+void free_scene_buffers(pt_context *c) {
+    for (int i = 0; i < 2; ++i) { if (c->pool[i]) (void)hipFree(c->pool[i]); c->pool[i] = nullptr; }
+    if (c->image_own) (void)hipFree(c->image_own);
+    if (c->d_geoms) (void)hipFree(c->d_geoms);
+    if (c->d_mats) (void)hipFree(c->d_mats);
+    if (c->d_status) (void)hipFree(c->d_status);
+    if (c->d_display) (void)hipFree(c->d_display);
+    c->image_own = nullptr; c->d_geoms = nullptr; c->d_mats = nullptr; c->d_status = nullptr; c->d_display = nullptr;
+    c->scene_ready = false;
+}
+
+template <bool LDS, bool LAST>
+int launch_bounce_t(pt_context *c, const BounceArgs &a) {
+    hipLaunchKernelGGL((k_bounce<LDS, LAST>), dim3(c->grid_bounce), dim3(kBlock), c->lds_bytes, c->stream, a,
+                       (const GeomRec *)c->d_geoms, (const MatRec *)c->d_mats);
+    HIPCHK(hipGetLastError());
+    return PT_OK;
+}
+
+int launch_bounce(pt_context *c, const BounceArgs &a, bool last) {
+    Scoped s(c, 1);
+    if (c->geom_lds) return last ? launch_bounce_t<true, true>(c, a) : launch_bounce_t<true, false>(c, a);
+    return last ? launch_bounce_t<false, true>(c, a) : launch_bounce_t<false, false>(c, a);
+}
+
+// one iteration; stop_after < 0 renders all bounces, otherwise only the first `stop_after`
+// bounces without the LAST variant (parity hook)
+int enqueue_iteration(pt_context *c, uint32_t iteration, int stop_after) {
+    const int D = c->cfg.max_depth;
+    {
+        Scoped s(c, 0);
+        GenArgs g;
+        g.cam = c->cam; g.pool = c->pool[0]; g.cap = c->cap; g.n_own = c->n_own; g.iteration = iteration;
+        g.sync = c->d_sync; g.status = c->d_status; g.status_words = c->status_words; g.depth = D;
+        const uint32_t work = c->n_own > c->status_words ? c->n_own : c->status_words;
+        hipLaunchKernelGGL(k_generate, dim3((work + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, g);
+        HIPCHK(hipGetLastError());
+    }
+    const int nb = stop_after < 0 ? D : stop_after;
+    for (int b = 0; b < nb; ++b) {
+        BounceArgs a;
+        a.in = c->pool[b & 1]; a.out = c->pool[(b + 1) & 1]; a.cap = c->cap; a.image = c->image;
+        a.G = c->G; a.M = c->M;
+        a.sync = c->d_sync; a.status = c->d_status + (size_t)b * c->max_chunks;
+        a.rpt = c->rpt; a.bounce = b; a.iteration = iteration;
+        const bool last = (stop_after < 0) && (b == D - 1);
+        int rc = launch_bounce(c, a, last);
+        if (rc) return rc;
+    }
+    c->counts_pending = true;
+    return PT_OK;
+}
+
+int check_device_error(pt_context *c) {
+    uint32_t err = 0;
+    HIPCHK(hipMemcpy(&err, &c->d_sync->error, sizeof err, hipMemcpyDeviceToHost));
+    if (err) { pth::set_error("compaction look-back exceeded its spin limit (device sync state corrupt)"); return PT_ERR_HIP; }
+    return PT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int pt_create(const pt_config *cfg, pt_context **out) {
+    if (!cfg || !out) { pth::set_error("pt_create: null argument"); return PT_ERR_ARGUMENT; }
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        pth::set_error("pt_create: no HIP device visible (this library has no CPU fallback)");
+        return PT_ERR_NO_DEVICE;
+    }
+    if (cfg->device < 0 || cfg->device >= n) { pth::set_error("pt_create: device %d out of range (%d visible)", cfg->device, n); return PT_ERR_ARGUMENT; }
+    if (cfg->max_depth < 1 || cfg->max_depth > 64) { pth::set_error("pt_create: max_depth %d not in 1..64", cfg->max_depth); return PT_ERR_ARGUMENT; }
+    if (cfg->row_stride < 1 || cfg->row_offset < 0 || cfg->row_offset >= cfg->row_stride) { pth::set_error("pt_create: bad row_offset/row_stride"); return PT_ERR_ARGUMENT; }
+    HIPCHK(hipSetDevice(cfg->device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, cfg->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        pth::set_error("pt_create: device %d is %s; this library carries gfx950 code objects only", cfg->device, prop.gcnArchName);
+        return PT_ERR_NO_DEVICE;
+    }
+    pt_context *c = new pt_context();
+    c->cfg = *cfg;
+    c->n_cu = prop.multiProcessorCount;
+    c->geom_lds = (cfg->geometry_path == 0);
+    int chunk = cfg->chunk_rays > 0 ? cfg->chunk_rays : 768;
+    c->rpt = (uint32_t)((chunk + kBlock - 1) / kBlock);
+    if (c->rpt < 1) c->rpt = 1;
+    if (c->rpt > 8) c->rpt = 8;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; pth::set_error("hipStreamCreate failed"); return PT_ERR_HIP; }
+    if (hipMalloc(&c->d_sync, sizeof(SyncBlock)) != hipSuccess) { delete c; pth::set_error("hipMalloc(sync) failed"); return PT_ERR_HIP; }
+    (void)hipMemset(c->d_sync, 0, sizeof(SyncBlock));
+    *out = c;
+    return PT_OK;
+}
+
+void pt_destroy(pt_context *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_scene_buffers(c);
+    if (c->d_sync) (void)hipFree(c->d_sync);
+    for (auto &e : c->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto e : c->free_events) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_material *mats, int M, const pt_camera *cam) {
+    if (!c || !geoms || !mats || !cam || G < 1 || M < 1) { pth::set_error("pt_upload_scene: bad argument"); return PT_ERR_ARGUMENT; }
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const int W = (int)cam->resolution[0], H = (int)cam->resolution[1];
+    if (W < 2 || H < 2 || (int64_t)W * H > (1ll << 30)) { pth::set_error("pt_upload_scene: resolution %dx%d unsupported", W, H); return PT_ERR_ARGUMENT; }
+    std::vector<GeomRec> g(G);
+    std::vector<MatRec> m(M);
+    for (int i = 0; i < M; ++i) {
+        memset(&m[i], 0, sizeof(MatRec));
+        memcpy(m[i].color, mats[i].color, 12);
+        m[i].emittance = mats[i].emittance;
+        memcpy(m[i].spec, mats[i].specularColor, 12);
+        m[i].refl = mats[i].hasReflective;
+        m[i].refr = mats[i].hasRefractive;
+        m[i].ior = mats[i].indexOfRefraction;
+    }
+    for (int i = 0; i < G; ++i) {
+        if (geoms[i].materialid < 0 || geoms[i].materialid >= M) { pth::set_error("pt_upload_scene: geom %d has materialid %d (have %d materials)", i, geoms[i].materialid, M); return PT_ERR_ARGUMENT; }
+        memcpy(g[i].inv, geoms[i].inverseTransform, 48);
+        memcpy(g[i].xf, geoms[i].transform, 48);
+        g[i].type = geoms[i].type;
+        g[i].mat = geoms[i].materialid;
+        g[i].inside_hits = mats[geoms[i].materialid].hasRefractive > 0.0f ? 1 : 0;
+        g[i].pad = 0;
+    }
+    const int stride = c->cfg.row_stride, offset = c->cfg.row_offset;
+    const int rows = (H - offset + stride - 1) / stride;
+    const uint32_t n_own = (uint32_t)rows * (uint32_t)W;
+    const bool realloc = !c->scene_ready || W != c->W || H != c->H || G != c->G || M != c->M;
+    if (realloc) {
+        free_scene_buffers(c);
+        c->W = W; c->H = H; c->G = G; c->M = M;
+        c->n_own = n_own;
+        const uint32_t chunk_rays = kBlock * c->rpt;
+        c->max_chunks = (n_own + chunk_rays - 1) / chunk_rays;
+        c->cap = c->max_chunks * chunk_rays;              // whole chunks: loads never need a tail guard on cap
+        for (int i = 0; i < 2; ++i) HIPCHK(hipMalloc(&c->pool[i], (size_t)c->cap * kFields * sizeof(float)));
+        HIPCHK(hipMalloc(&c->image_own, (size_t)W * H * 3 * sizeof(float)));
+        HIPCHK(hipMemset(c->image_own, 0, (size_t)W * H * 3 * sizeof(float)));
+        if (!c->image) c->image = c->image_own;
+        HIPCHK(hipMalloc(&c->d_geoms, (size_t)G * sizeof(GeomRec)));
+        HIPCHK(hipMalloc(&c->d_mats, (size_t)M * sizeof(MatRec)));
+        c->status_words = (uint32_t)c->cfg.max_depth * c->max_chunks;
+        HIPCHK(hipMalloc(&c->d_status, (size_t)c->status_words * sizeof(u64)));
+        HIPCHK(hipMemset(c->d_status, 0, (size_t)c->status_words * sizeof(u64)));
+        HIPCHK(hipMalloc(&c->d_display, (size_t)W * H * sizeof(uchar4)));
+    }
+    HIPCHK(hipMemcpy(c->d_geoms, g.data(), (size_t)G * sizeof(GeomRec), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_mats, m.data(), (size_t)M * sizeof(MatRec), hipMemcpyHostToDevice));
+    pth::camera_basis(cam, &c->cfg, &c->cam);
+
+    // LDS budget and persistent grid
+    c->geom_lds = (c->cfg.geometry_path == 0);
+    uint32_t tb = tables_bytes(G, M, c->geom_lds);
+    const uint32_t stage_bytes = kBlock * c->rpt * kFields * sizeof(float);
+    if (c->geom_lds && tb + stage_bytes > 160u * 1024u) {   // table too large for LDS next to the stage
+        c->geom_lds = false;
+        tb = tables_bytes(G, M, false);
+    }
+    c->lds_bytes = tb + stage_bytes;
+    if (c->lds_bytes > 64u * 1024u) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bounce<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bounce<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bounce<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bounce<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    int per_cu = c->cfg.blocks_per_cu;
+    if (per_cu <= 0) {
+        int occ = 0;
+        const void *fn = c->geom_lds ? reinterpret_cast<const void *>(&k_bounce<true, false>)
+                                     : reinterpret_cast<const void *>(&k_bounce<false, false>);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, kBlock, c->lds_bytes) != hipSuccess || occ < 1) occ = 2;
+        per_cu = occ;
+    }
+    int grid = c->n_cu * per_cu;
+    if ((uint32_t)grid > c->max_chunks) grid = (int)c->max_chunks;
+    if (grid < 1) grid = 1;
+    c->grid_bounce = grid;
+    c->scene_ready = true;
+    return PT_OK;
+}
+
+int pt_set_image(pt_context *c, const float *host_rgb) {
+    if (!c || !c->scene_ready) { pth::set_error("pt_set_image: no scene uploaded"); return PT_ERR_STATE; }
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const size_t bytes = (size_t)c->W * c->H * 3 * sizeof(float);
+    if (host_rgb) HIPCHK(hipMemcpy(c->image, host_rgb, bytes, hipMemcpyHostToDevice));
+    else HIPCHK(hipMemset(c->image, 0, bytes));
+    return PT_OK;
+}
+
+int pt_bind_device_image(pt_context *c, void *device_rgb) {
+    if (!c) { pth::set_error("pt_bind_device_image: null context"); return PT_ERR_ARGUMENT; }
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->image = device_rgb ? static_cast<float *>(device_rgb) : c->image_own;
+    return PT_OK;
+}
+
+int pt_get_image(pt_context *c, float *host_rgb) {
+    if (!c || !c->scene_ready || !host_rgb) { pth::set_error("pt_get_image: bad state/argument"); return PT_ERR_STATE; }
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(host_rgb, c->image, (size_t)c->W * c->H * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return check_device_error(c);
+}
+
+int pt_render(pt_context *c, int first_iteration, int count) {
+    if (!c || !c->scene_ready) { pth::set_error("pt_render: no scene uploaded"); return PT_ERR_STATE; }
+    if (first_iteration < 1 || count < 0) { pth::set_error("pt_render: iterations are 1-based"); return PT_ERR_ARGUMENT; }
+    HIPCHK(hipSetDevice(c->cfg.device));
+    for (int it = first_iteration; it < first_iteration + count; ++it) {
+        if (c->cfg.mode == 1) {
+            Scoped s(c, 1);
+            FlatArgs f;
+            memset(&f, 0, sizeof f);
+            f.cam = c->cam; f.image = c->image; f.geoms = c->d_geoms; f.mats = c->d_mats; f.G = c->G; f.M = c->M;
+            f.n_own = c->n_own; f.write_image = 1;
+            hipLaunchKernelGGL(k_flat, dim3((c->n_own + kBlock - 1) / kBlock), dim3(kBlock), tables_bytes(c->G, c->M, true), c->stream, f);
+            HIPCHK(hipGetLastError());
+        } else {
+            int rc = enqueue_iteration(c, (uint32_t)it, -1);
+            if (rc) return rc;
+        }
+        c->iterations++;
+    }
+    return PT_OK;
+}
+
+int pt_sync(pt_context *c) {
+    if (!c) { pth::set_error("pt_sync: null context"); return PT_ERR_ARGUMENT; }
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int rc = resolve_events(c);
+    if (rc) return rc;
+    return check_device_error(c);
+}
+
+int pt_display(pt_context *c, float scale, void *out, int out_is_device) {
+    if (!c || !c->scene_ready) { pth::set_error("pt_display: no scene uploaded"); return PT_ERR_STATE; }
+    if (!out) return PT_OK;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    const uint32_t n = (uint32_t)c->W * c->H;
+    uchar4 *dst = out_is_device ? static_cast<uchar4 *>(out) : c->d_display;
+    {
+        Scoped s(c, 2);
+        hipLaunchKernelGGL(k_display, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->image, dst, n, scale);
+        HIPCHK(hipGetLastError());
+    }
+    if (!out_is_device) {
+        HIPCHK(hipMemcpyAsync(out, c->d_display, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return PT_OK;
+}
+
+int pt_set_profiling(pt_context *c, int enabled) {
+    if (!c) { pth::set_error("pt_set_profiling: null context"); return PT_ERR_ARGUMENT; }
+    int rc = pt_sync(c);
+    if (rc) return rc;
+    c->cfg.profile = enabled ? 1 : 0;
+    return PT_OK;
+}
+
+int pt_get_stats(pt_context *c, pt_stats *out) {
+    if (!c || !out) { pth::set_error("pt_get_stats: null argument"); return PT_ERR_ARGUMENT; }
+    int rc = pt_sync(c);
+    if (rc) return rc;
+    SyncBlock h;
+    HIPCHK(hipMemcpy(&h, c->d_sync, sizeof h, hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof *out);
+    out->generate_ms = c->ms[0]; out->bounce_ms = c->ms[1]; out->display_ms = c->ms[2];
+    out->generate_launches = c->launches[0]; out->bounce_launches = c->launches[1]; out->display_launches = c->launches[2];
+    out->iterations = c->iterations;
+    for (int k = 0; k <= c->cfg.max_depth && k < 65; ++k) out->live[k] = h.totals[k] + (c->counts_pending ? h.counts[k] : 0);
+    out->emitted = h.emitted;
+    return PT_OK;
+}
+
+int pt_reset_stats(pt_context *c) {
+    if (!c) { pth::set_error("pt_reset_stats: null context"); return PT_ERR_ARGUMENT; }
+    int rc = pt_sync(c);
+    if (rc) return rc;
+    HIPCHK(hipMemset(c->d_sync, 0, sizeof(SyncBlock)));
+    c->counts_pending = false;
+    c->ms[0] = c->ms[1] = c->ms[2] = 0;
+    c->launches[0] = c->launches[1] = c->launches[2] = 0;
+    c->iterations = 0;
+    return PT_OK;
+}
+
+int pt_get_resolution(pt_context *c, int *w, int *h, int *owned) {
+    if (!c || !c->scene_ready) { pth::set_error("pt_get_resolution: no scene uploaded"); return PT_ERR_STATE; }
+    if (w) *w = c->W;
+    if (h) *h = c->H;
+    if (owned) *owned = (int)c->n_own;
+    return PT_OK;
+}
+
+// ---------------------------------------------------------------- parity hooks ---------
+
+int pt_debug_primary_hits(pt_context *c, float *dir, int *hit, float *t, float *P, float *N) {
+    if (!c || !c->scene_ready) { pth::set_error("pt_debug_primary_hits: no scene uploaded"); return PT_ERR_STATE; }
+    HIPCHK(hipSetDevice(c->cfg.device));
+    const size_t n = (size_t)c->W * c->H;
+    float *d_dir = nullptr, *d_t = nullptr, *d_P = nullptr, *d_N = nullptr;
+    int *d_hit = nullptr;
+    HIPCHK(hipMalloc(&d_dir, n * 12)); HIPCHK(hipMalloc(&d_P, n * 12)); HIPCHK(hipMalloc(&d_N, n * 12));
+    HIPCHK(hipMalloc(&d_t, n * 4)); HIPCHK(hipMalloc(&d_hit, n * 4));
+    HIPCHK(hipMemset(d_hit, 0xFF, n * 4));
+    FlatArgs f;
+    memset(&f, 0, sizeof f);
+    f.cam = c->cam; f.image = c->image; f.geoms = c->d_geoms; f.mats = c->d_mats; f.G = c->G; f.M = c->M;
+    f.n_own = c->n_own; f.write_image = 0;
+    f.dir = d_dir; f.t = d_t; f.P = d_P; f.N = d_N; f.hit = d_hit;
+    hipLaunchKernelGGL(k_flat, dim3((c->n_own + kBlock - 1) / kBlock), dim3(kBlock), tables_bytes(c->G, c->M, true), c->stream, f);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (dir) HIPCHK(hipMemcpy(dir, d_dir, n * 12, hipMemcpyDeviceToHost));
+    if (P) HIPCHK(hipMemcpy(P, d_P, n * 12, hipMemcpyDeviceToHost));
+    if (N) HIPCHK(hipMemcpy(N, d_N, n * 12, hipMemcpyDeviceToHost));
+    if (t) HIPCHK(hipMemcpy(t, d_t, n * 4, hipMemcpyDeviceToHost));
+    if (hit) HIPCHK(hipMemcpy(hit, d_hit, n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d_dir); (void)hipFree(d_P); (void)hipFree(d_N); (void)hipFree(d_t); (void)hipFree(d_hit);
+    return PT_OK;
+}
+
+int pt_debug_trace_pool(pt_context *c, int iteration, int bounces, int *count, float *ox, float *oy, float *oz,
+                        float *dx, float *dy, float *dz, float *tr, float *tg, float *tb, uint32_t *pixel) {
+    if (!c || !c->scene_ready || c->cfg.mode != 0) { pth::set_error("pt_debug_trace_pool: needs a path-trace context with a scene"); return PT_ERR_STATE; }
+    if (bounces < 0 || bounces > c->cfg.max_depth || iteration < 1) { pth::set_error("pt_debug_trace_pool: bad bounces/iteration"); return PT_ERR_ARGUMENT; }
+    HIPCHK(hipSetDevice(c->cfg.device));
+    // render into a scratch accumulator so that the hook leaves the image untouched
+    float *saved = c->image, *scratch = nullptr;
+    HIPCHK(hipMalloc(&scratch, (size_t)c->W * c->H * 3 * sizeof(float)));
+    HIPCHK(hipMemset(scratch, 0, (size_t)c->W * c->H * 3 * sizeof(float)));
+    c->image = scratch;
+    int rc = enqueue_iteration(c, (uint32_t)iteration, bounces);
+    c->image = saved;
+    if (rc) { (void)hipFree(scratch); return rc; }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)hipFree(scratch);
+    uint32_t n = 0;
+    HIPCHK(hipMemcpy(&n, &c->d_sync->counts[bounces], 4, hipMemcpyDeviceToHost));
+    // this hook's counts must not pollute the stats
+    HIPCHK(hipMemset(c->d_sync->counts, 0, sizeof(uint32_t) * 72));
+    c->counts_pending = false;
+    if (count) *count = (int)n;
+    const float *src = c->pool[bounces & 1];
+    float *dst[9] = {ox, oy, oz, dx, dy, dz, tr, tg, tb};
+    for (int f = 0; f < 9; ++f)
+        if (dst[f] && n) HIPCHK(hipMemcpy(dst[f], src + (size_t)f * c->cap, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (pixel && n) HIPCHK(hipMemcpy(pixel, src + (size_t)9 * c->cap, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return check_device_error(c);
+}
+
+int pt_debug_rng_from_thread(pt_context *c, float resx, float resy, float time, int n, const int *xy, float *out3) {
+    (void)resy;
+    if (!c || n < 0 || !xy || !out3) { pth::set_error("pt_debug_rng_from_thread: bad argument"); return PT_ERR_ARGUMENT; }
+    if (n == 0) return PT_OK;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    int *d_xy = nullptr; float *d_out = nullptr;
+    HIPCHK(hipMalloc(&d_xy, (size_t)n * 8)); HIPCHK(hipMalloc(&d_out, (size_t)n * 12));
+    HIPCHK(hipMemcpy(d_xy, xy, (size_t)n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_rng_from_thread, dim3((n + 255) / 256), dim3(256), 0, c->stream, resx, time, n, d_xy, d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out3, d_out, (size_t)n * 12, hipMemcpyDeviceToHost));
+    (void)hipFree(d_xy); (void)hipFree(d_out);
+    return PT_OK;
+}
+
+int pt_debug_hemisphere(pt_context *c, int n, const float *normal3, const float *xi2, float *out3) {
+    if (!c || n < 0 || !normal3 || !xi2 || !out3) { pth::set_error("pt_debug_hemisphere: bad argument"); return PT_ERR_ARGUMENT; }
+    if (n == 0) return PT_OK;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    float *d_n = nullptr, *d_x = nullptr, *d_o = nullptr;
+    HIPCHK(hipMalloc(&d_n, (size_t)n * 12)); HIPCHK(hipMalloc(&d_x, (size_t)n * 8)); HIPCHK(hipMalloc(&d_o, (size_t)n * 12));
+    HIPCHK(hipMemcpy(d_n, normal3, (size_t)n * 12, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_x, xi2, (size_t)n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_hemisphere, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, d_n, d_x, d_o);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out3, d_o, (size_t)n * 12, hipMemcpyDeviceToHost));
+    (void)hipFree(d_n); (void)hipFree(d_x); (void)hipFree(d_o);
+    return PT_OK;
+}
+
+int pt_debug_sincos(pt_context *c, int n, const float *a, float *s, float *co) {
+    if (!c || n < 0 || !a || !s || !co) { pth::set_error("pt_debug_sincos: bad argument"); return PT_ERR_ARGUMENT; }
+    if (n == 0) return PT_OK;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    float *d_a = nullptr, *d_s = nullptr, *d_c = nullptr;
+    HIPCHK(hipMalloc(&d_a, (size_t)n * 4)); HIPCHK(hipMalloc(&d_s, (size_t)n * 4)); HIPCHK(hipMalloc(&d_c, (size_t)n * 4));
+    HIPCHK(hipMemcpy(d_a, a, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_sincos, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, d_a, d_s, d_c);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(s, d_s, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(co, d_c, (size_t)n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d_a); (void)hipFree(d_s); (void)hipFree(d_c);
+    return PT_OK;
+}
+
+}  // extern "C"

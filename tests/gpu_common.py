@@ -1,0 +1,42 @@
+"""Helpers shared by the -m gpu parity tests: golden scene -> product PODs, oracle <-> GPU configs."""
+import ctypes as C
+
+import numpy as np
+
+import orc
+from conftest import load_package
+
+
+def to_product(scene):
+    """orc.Scene (reference-parser PODs) -> (Geom[], Material[], Camera) of the product ABI."""
+    pkg = load_package()
+    geoms = (pkg.Geom * scene.G)()
+    for i, g in enumerate(scene.geoms):
+        geoms[i].type, geoms[i].materialid = g.type, g.materialid
+        for k in range(12):
+            geoms[i].transform[k] = g.transform[k]
+            geoms[i].inverseTransform[k] = g.inverseTransform[k]
+    mats = (pkg.Material * scene.M)()
+    for i, m in enumerate(scene.materials):
+        C.memmove(C.byref(mats[i]), C.byref(m), 64)
+    cam = pkg.Camera()
+    C.memmove(C.byref(cam), C.byref(scene.camera), 52)
+    return geoms, mats, cam
+
+
+def make_tracer(scene, depth=8, **kw):
+    pkg = load_package()
+    cfg = pkg.default_config(max_depth=depth, **kw)
+    tr = pkg.PathTracer(cfg)
+    tr.upload(*to_product(scene))
+    return tr
+
+
+def oracle_config(depth=8, **kw):
+    return orc.default_config(depth, **kw)
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.sqrt(np.mean((a - b) ** 2)))

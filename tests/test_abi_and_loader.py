@@ -1,0 +1,155 @@
+"""CPU-side checks of the product library: it loads, exports every symbol include/ptmi355.h
+declares, refuses to render without a GPU (no fallback), and its host-side scene loader /
+transform builder / image writer agree with the REFERENCE's own code (tests/golden/ref_*.json,
+produced by oracle/_ref = reference scene.cpp + utilities.cpp + image.cpp compiled where they lie)."""
+import ctypes as C
+import json
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+import orc
+from conftest import ROOT, load_package
+
+
+@pytest.fixture(scope="module")
+def pkg(pt):
+    return pt
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    hdr = open(os.path.join(ROOT, "include", "ptmi355.h")).read()
+    declared = sorted(set(re.findall(r"\b(pt_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 30
+    L = C.CDLL(pkg.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), "libptmi355.so does not export %s" % name
+    assert sorted(pkg.EXPORTS) == declared
+    assert pkg.lib().pt_abi_version() == 1
+
+
+def test_pod_sizes_match_reference_structs(pkg):
+    sizes = json.load(open(os.path.join(orc.GOLD, "ref_scene_sampleScene.json")))["sizeof"]
+    assert C.sizeof(pkg.Material) == sizes["material"] == 64
+    assert C.sizeof(pkg.Camera) == sizes["cameraData"] == 52
+    assert C.sizeof(pkg.Geom) == 104
+    assert sizes["staticGeom"] == 172 and sizes["cudaMat4"] == 64 and sizes["ray"] == 24
+
+
+def test_no_cpu_fallback(pkg):
+    """Without a gfx950 device the product must fail loudly, not render on the CPU."""
+    if pkg.lib().pt_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.PtError) as e:
+        pkg.PathTracer()
+    assert "no HIP device" in str(e.value)
+    assert pkg.lib().pt_render(None, 1, 1) != 0
+
+
+def test_product_tree_never_references_the_oracle():
+    for base, _, files in os.walk(os.path.join(ROOT, "project2-pathtracer_amd")):
+        for f in files:
+            if f.endswith((".hip", ".hpp", ".cpp", ".h", ".py", "Makefile")):
+                text = open(os.path.join(base, f), errors="replace").read()
+                assert "pt_oracle" not in text and "libpt_oracle" not in text and "oracle/" not in text, f
+    hdr = open(os.path.join(ROOT, "include", "ptmi355.h")).read()
+    assert "oracle" not in hdr
+
+
+SCENES = ["cornell", "cornell_c1", "cornell_mirror", "cornell_glass_4k", "random256"]
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_scene_loader_matches_reference_parser(pkg, name):
+    gold = json.load(open(os.path.join(orc.GOLD, "ref_scene_%s.json" % name)))
+    sf = pkg.SceneFile(os.path.join(ROOT, "scenes", name + ".txt"))
+    assert sf.ngeoms == len(gold["objects"]) and sf.nmaterials == len(gold["materials"])
+    assert sf.nframes == gold["camera"]["frames"] and sf.iterations == gold["camera"]["iterations"]
+    assert sf.image_name == gold["camera"]["imageName"]
+    for frame in range(sf.nframes):
+        geoms, mats, cam = sf.flatten(frame)
+        for i, m in enumerate(gold["materials"]):
+            assert bytes(mats[i]) == struct.pack("<16I", *m)
+        for i, o in enumerate(gold["objects"]):
+            fr = o["frames"][frame]
+            assert geoms[i].type == o["type"] and geoms[i].materialid == o["materialid"]
+            xf, inv = sf.object_matrices(i, frame)
+            assert np.array_equal(xf, np.array(fr["transform"], np.uint32).view(np.float32))
+            assert np.array_equal(inv, np.array(fr["inverseTransform"], np.uint32).view(np.float32))
+            assert np.array_equal(np.array(list(geoms[i].transform), np.float32), xf[:12])
+            assert np.array_equal(np.array(list(geoms[i].inverseTransform), np.float32), inv[:12])
+            # the w row the C ABI drops is (0,0,0,1) for every matrix the parser builds
+            assert list(xf[12:]) == [0, 0, 0, 1] and list(inv[12:]) == [0, 0, 0, 1]
+        c = gold["camera"]
+        assert [orc.bits_from_f32(v) for v in cam.resolution] == c["resolution"]
+        assert [orc.bits_from_f32(v) for v in cam.fov] == c["fov"]
+        assert [orc.bits_from_f32(v) for v in cam.position] == c["positions"][frame]
+        assert [orc.bits_from_f32(v) for v in cam.view] == c["views"][frame]
+        assert [orc.bits_from_f32(v) for v in cam.up] == c["ups"][frame]
+
+
+def test_our_cornell_equals_reference_sample_scene():
+    a = json.load(open(os.path.join(orc.GOLD, "ref_scene_sampleScene.json")))
+    b = json.load(open(os.path.join(orc.GOLD, "ref_scene_cornell.json")))
+    for k in ("materials", "objects", "camera", "sizeof"):
+        assert a[k] == b[k]
+
+
+def test_build_transform_matches_reference(pkg):
+    T = json.load(open(os.path.join(orc.GOLD, "ref_transforms.json")))
+    for case in T["cases"]:
+        xf, inv = pkg.build_transform(case["t"], case["r"], case["s"])
+        assert np.array_equal(xf, np.array(case["transform"], np.uint32).view(np.float32)), case
+        assert np.array_equal(inv, np.array(case["inverseTransform"], np.uint32).view(np.float32)), case
+
+
+def test_loader_error_behaviour(pkg, tmp_path):
+    with pytest.raises(pkg.PtError):
+        pkg.SceneFile(str(tmp_path / "missing.txt"))
+    good = open(os.path.join(ROOT, "scenes", "cornell_c1.txt")).read()
+    bad_id = tmp_path / "bad_id.txt"
+    bad_id.write_text(good.replace("MATERIAL 3", "MATERIAL 7", 1))
+    with pytest.raises(pkg.PtError) as e:
+        pkg.SceneFile(str(bad_id))
+    assert "MATERIAL ID does not match" in str(e.value)       # the reference's message (scene.cpp:223)
+    bad_type = tmp_path / "bad_type.txt"
+    bad_type.write_text(good.replace("\nsphere\n", "\nsphere \n", 1))   # whole-line strcmp (scene.cpp:48)
+    with pytest.raises(pkg.PtError) as e:
+        pkg.SceneFile(str(bad_type))
+    assert "is not a valid object type" in str(e.value)
+    bad_frame = tmp_path / "bad_frame.txt"
+    bad_frame.write_text(good.replace("frame 1", "frame 5", 1))
+    with pytest.raises(pkg.PtError) as e:
+        pkg.SceneFile(str(bad_frame))
+    assert "Incorrect frame count" in str(e.value)
+    # trailing //comments are ignored tokens, keys may come in any order, CRLF breaks only type lines
+    commented = tmp_path / "commented.txt"
+    commented.write_text(good.replace("MATERIAL 0\n", "MATERIAL 0\t\t//white diffuse\n", 1))
+    sf = pkg.SceneFile(str(commented))
+    assert sf.nmaterials == 9
+
+
+def test_image_writer_matches_reference_image_class(pkg, tmp_path):
+    meta = json.load(open(os.path.join(orc.GOLD, "ref_image_meta.json")))
+    W, H = meta["W"], meta["H"]
+    src = np.fromfile(os.path.join(orc.GOLD, "ref_image_in.f32"), np.float32).reshape(H, W, 3)
+    out = tmp_path / "out.bmp"
+    pkg.image_save(str(out), src, meta["divisor"], np.float32(meta["gamma"]))
+    assert out.read_bytes() == open(os.path.join(orc.GOLD, "ref_image_out.bmp"), "rb").read()   # byte-exact BMP
+    from PIL import Image
+    png = tmp_path / "out.png"
+    pkg.image_save(str(png), src, meta["divisor"], np.float32(meta["gamma"]))
+    ours = np.asarray(Image.open(str(png)).convert("RGB"))
+    ref = np.asarray(Image.open(os.path.join(orc.GOLD, "ref_image_out.png")).convert("RGB"))
+    assert np.array_equal(ours, ref)                    # same pixels (our PNG stores, stb deflates)
+    assert np.array_equal(pkg.image_to_u8(src, meta["divisor"], np.float32(meta["gamma"])), ref)
+
+
+def test_tokenizer_cases_from_reference(pkg):
+    # the loader's tokenisation is whitespace splitting exactly like utilityCore::tokenizeString
+    T = json.load(open(os.path.join(orc.GOLD, "ref_tokens.json")))
+    for case in T["cases"]:
+        assert case["line"].split() == case["tokens"]

@@ -1,0 +1,263 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle on identical seeds.
+
+Bar: every kernel here is integer/IEEE-binary32 work with a fixed expression order on both
+sides, so the comparison is BIT-EXACT (numpy == on float32, i.e. -0 == +0) unless a test states
+a tolerance.  The north-star image tolerance (L2 error < 1e-4 per channel) is asserted too."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import orc
+from gpu_common import make_tracer, oracle_config, rel_l2, to_product
+
+pytestmark = pytest.mark.gpu
+
+K = json.load(open(os.path.join(orc.GOLD, "survey_kats.json")))
+
+
+@pytest.fixture(scope="module")
+def cornell200():
+    return orc.load_golden_scene("sampleScene").with_resolution(200, 200)
+
+
+def test_device_present_and_native_library_loaded(pt):
+    assert pt.lib().pt_device_count() >= 1
+    tr = pt.PathTracer()
+    tr.close()
+
+
+def test_rng_from_thread_kat_and_sweep(pt, cornell200):
+    tr = make_tracer(cornell200)
+    r = K["rng_from_thread"]
+    out = tr.rng_from_thread(800, 800, r["time"], [[r["x"], r["y"]]])
+    for got, want in zip(out[0], r["out"]):
+        assert float("%.9g" % got) == want
+    xy = np.stack(np.meshgrid(np.arange(0, 800, 37), np.arange(0, 800, 41)), -1).reshape(-1, 2)
+    got = tr.rng_from_thread(800, 800, 5.0, xy)
+    want = np.zeros_like(got)
+    o = (C.c_float * 3)()
+    for i, (x, y) in enumerate(xy):
+        orc.lib().orc_rng_from_thread(800, 800, 5.0, int(x), int(y), o)
+        want[i] = list(o)
+    assert np.array_equal(got, want)
+
+
+def test_sincos_polynomial_bit_exact(pt, cornell200):
+    tr = make_tracer(cornell200)
+    rng = np.random.default_rng(1)
+    a = np.concatenate([rng.random(200000).astype(np.float32) * np.float32(6.2831855),
+                        np.array([0, 6.2831855, 3.1415927, 1.5707964, 4.712389, 1e-30, 0.7853982], np.float32)])
+    s, c = tr.sincos(a)
+    ws, wc = np.zeros_like(a), np.zeros_like(a)
+    L = orc.lib()
+    sv, cv = C.c_float(), C.c_float()
+    for i in range(0, len(a), 97):                      # sample (python loop), bit-exact
+        L.orc_sincos(a[i], C.byref(sv), C.byref(cv))
+        assert s[i] == sv.value and c[i] == cv.value
+    # and accurate: within 2e-7 of the true values everywhere
+    assert np.abs(s - np.sin(a.astype(np.float64))).max() < 2e-7
+    assert np.abs(c - np.cos(a.astype(np.float64))).max() < 2e-7
+
+
+def test_hemisphere_bit_exact(pt, cornell200):
+    tr = make_tracer(cornell200)
+    rng = np.random.default_rng(2)
+    n = rng.normal(size=(5000, 3)).astype(np.float32)
+    n /= np.linalg.norm(n, axis=1, keepdims=True).astype(np.float32)
+    n[:6] = [[0, 1, 0], [1, 0, 0], [0, 0, 1], [0, -1, 0], [-1, 0, 0], [0, 0, -1]]
+    xi = rng.random((5000, 2)).astype(np.float32)
+    xi[0] = [0.25, 0.5]
+    got = tr.hemisphere(n, xi)
+    want = np.zeros_like(got)
+    o = (C.c_float * 3)()
+    for i in range(len(n)):
+        orc.lib().orc_hemisphere(orc.vec3(*n[i]), xi[i, 0], xi[i, 1], o)
+        want[i] = list(o)
+    assert np.array_equal(got, want)
+    for g, w in zip(got[0], K["hemisphere"]["out"]):
+        assert float("%.9g" % g) == w
+
+
+def test_primary_hits_bit_exact_and_reference_kats(pt):
+    sc = orc.load_golden_scene("sampleScene")          # 800x800, the survey's KAT configuration
+    tr = make_tracer(sc)
+    d, hit, t, P, N = tr.primary_hits()
+    for h in K["primary_hits_800"]:
+        idx = h["pixel"][0] + h["pixel"][1] * 800
+        assert hit[idx] == h["obj"]
+        for g, w in zip(d[idx], h["dir"]):
+            assert float("%.9g" % g) == w
+        if sc.geoms[h["obj"]].type == 1:
+            assert float("%.9g" % t[idx]) == h["t"]
+    # every pixel against the oracle, bit for bit
+    L = orc.lib()
+    cb = orc.CameraBasis()
+    L.orc_camera_setup(C.byref(sc.camera), C.byref(cb))
+    ga = sc.geom_array()
+    o, dd, PP, NN, tt = (C.c_float * 3)(), (C.c_float * 3)(), (C.c_float * 3)(), (C.c_float * 3)(), C.c_float()
+    rng = np.random.default_rng(3)
+    for idx in np.concatenate([rng.integers(0, 640000, 4000), [0, 799, 639999, 320400]]):
+        x, y = int(idx % 800), int(idx // 800)
+        L.orc_camera_ray(C.byref(cb), None, x, y, 0, 0, 0, 0, o, dd)
+        h = L.orc_nearest_hit(ga, sc.G, None, o, dd, C.byref(tt), PP, NN)
+        assert h == hit[idx]
+        assert np.array_equal(np.array(list(dd), np.float32), d[idx])
+        assert tt.value == t[idx]
+        assert np.array_equal(np.array(list(PP), np.float32), P[idx]) and np.array_equal(np.array(list(NN), np.float32), N[idx])
+    _, ohit = orc.raycast_flat(sc)
+    assert np.array_equal(ohit.reshape(-1), hit)
+
+
+def test_config1_reference_kernel_mode_matches_reference_image(pt):
+    """BASELINE config 1: 400x400, one hit, one iteration -- the reference kernel as shipped."""
+    sc = orc.load_golden_scene("cornell_c1")
+    tr = make_tracer(sc, depth=1, mode=1)
+    tr.set_image(None)
+    tr.render(1, 1)
+    img = tr.image()
+    want, _ = orc.raycast_flat(sc)
+    assert np.array_equal(img, want)
+    np.testing.assert_allclose(img.reshape(-1, 3).mean(0, dtype=np.float64), K["flat_image_mean_rgb"]["400"], atol=1e-6)
+    u8 = pt.image_to_u8(img, 1, np.float32(1.0 / 2.2))
+    assert hashlib.sha256(u8.tobytes()).hexdigest() == K["c1_bmp"]["raster_sha256"]
+    # sendImageToPBO
+    disp = tr.display(1.0)
+    o = (C.c_uint8 * 4)()
+    for idx in (0, 12345, 159999):
+        orc.lib().orc_display_pixel(orc.vec3(*img.reshape(-1, 3)[idx]), o)
+        assert list(disp.reshape(-1, 4)[idx]) == list(o)
+
+
+@pytest.mark.parametrize("bounces", [0, 1, 2, 5])
+def test_ray_pool_bit_exact_after_k_bounces(pt, cornell200, bounces):
+    """Stable compaction: the pool after k bounces equals the oracle's survivors in generation order."""
+    tr = make_tracer(cornell200)
+    n, arrs, pix = tr.trace_pool(3, bounces)
+    on, oarrs, opix = orc.trace_pool(cornell200, oracle_config(8), 3, bounces)
+    assert n == on
+    assert np.array_equal(pix, opix)
+    assert np.all(np.diff(pix.astype(np.int64)) > 0)    # sortedness: generation (pixel-major) order kept
+    for a, b in zip(arrs, oarrs):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("scene_name,depth,iters", [("sampleScene", 8, 6), ("cornell_mirror", 8, 4), ("cornell_glass_4k", 12, 4)])
+def test_image_and_live_counts_match_oracle(pt, scene_name, depth, iters):
+    sc = orc.load_golden_scene(scene_name).with_resolution(160, 120)
+    tr = make_tracer(sc, depth=depth)
+    tr.set_image(None)
+    tr.render(1, iters)
+    img = tr.image()
+    st = tr.stats()
+    want, live = orc.render(sc, oracle_config(depth), 1, iters)
+    assert [st.live[k] for k in range(depth + 1)] == [int(v) for v in live]
+    assert np.array_equal(img, want)                                   # bit-exact
+    for ch in range(3):                                                # the north-star tolerance
+        assert rel_l2(img[..., ch] / iters, want[..., ch] / iters) < 1e-4
+    assert not np.isnan(img).any()
+
+
+def test_accumulation_continues_from_host_image(pt, cornell200):
+    """camera::image is in/out: rendering 2+3 iterations with a host round trip == 5 in one go."""
+    tr = make_tracer(cornell200)
+    tr.set_image(None)
+    tr.render(1, 2)
+    part = tr.image()
+    tr.set_image(part)
+    tr.render(3, 3)
+    a = tr.image()
+    want, _ = orc.render(cornell200, oracle_config(8), 1, 5)
+    assert np.array_equal(a, want)
+
+
+@pytest.mark.parametrize("kw", [dict(geometry_path=1), dict(chunk_rays=256), dict(chunk_rays=1024), dict(blocks_per_cu=1)])
+def test_launch_variants_are_bit_identical(pt, cornell200, kw):
+    ref = make_tracer(cornell200)
+    ref.set_image(None); ref.render(1, 3)
+    var = make_tracer(cornell200, **kw)
+    var.set_image(None); var.render(1, 3)
+    assert np.array_equal(ref.image(), var.image())
+    n1, a1, p1 = ref.trace_pool(2, 3)
+    n2, a2, p2 = var.trace_pool(2, 3)
+    assert n1 == n2 and np.array_equal(p1, p2) and all(np.array_equal(x, y) for x, y in zip(a1, a2))
+
+
+def test_antialias_and_thin_lens_match_oracle(pt):
+    sc = orc.load_golden_scene("cornell_glass_4k").with_resolution(128, 72)
+    kw = dict(camera_mode=1, antialias=1, aperture=0.25, focal_distance=12.0)
+    tr = make_tracer(sc, depth=6, **kw)
+    tr.set_image(None); tr.render(1, 4)
+    want, live = orc.render(sc, oracle_config(6, **kw), 1, 4)
+    assert np.array_equal(tr.image(), want)
+    n, arrs, pix = tr.trace_pool(1, 0)
+    on, oarrs, opix = orc.trace_pool(sc, oracle_config(6, **kw), 1, 0)
+    assert n == on and all(np.array_equal(a, b) for a, b in zip(arrs, oarrs))
+
+
+def test_row_sharded_contexts_sum_to_the_full_frame(pt, cornell200):
+    """Multi-GPU decomposition on one device: shards own interleaved rows; summing the per-shard
+    accumulators (zeros elsewhere) is bit-identical to the unsharded render."""
+    full = make_tracer(cornell200)
+    full.set_image(None); full.render(1, 3)
+    want = full.image()
+    total = np.zeros_like(want)
+    owned = 0
+    for r in range(3):
+        sh = make_tracer(cornell200, row_offset=r, row_stride=3)
+        sh.set_image(None); sh.render(1, 3)
+        part = sh.image()
+        rows = np.arange(part.shape[0]) % 3 == r
+        assert not part[~rows].any()
+        total += part
+        owned += sh.owned
+    assert owned == 200 * 200
+    assert np.array_equal(total, want)
+
+
+def test_empty_and_tiny_inputs(pt):
+    """Edge cases: a scene whose rays all miss (live count drops to 0 after the first bounce), a
+    2x2 frame, a frame narrower than one wave."""
+    sc = orc.load_golden_scene("sampleScene").with_resolution(2, 2)
+    tr = make_tracer(sc)
+    tr.set_image(None); tr.render(1, 2)
+    want, live = orc.render(sc, oracle_config(8), 1, 2)
+    assert np.array_equal(tr.image(), want)
+    # camera looking away from everything: every primary ray misses
+    away = orc.load_golden_scene("sampleScene").with_resolution(37, 5)
+    away.camera.view[2] = 1.0
+    tr2 = make_tracer(away)
+    tr2.set_image(None); tr2.render(1, 2)
+    st = tr2.stats()
+    want2, live2 = orc.render(away, oracle_config(8), 1, 2)
+    assert [st.live[k] for k in range(9)] == [int(v) for v in live2]
+    assert st.live[1] == 0 and not tr2.image().any()
+
+
+def test_full_size_properties_1080p(pt):
+    """BASELINE config 3 size (1920x1080, 8 bounces, mirrors): properties that need no oracle run --
+    monotone live counts, sorted compacted pool, run-to-run determinism, shard sum == full."""
+    sc = orc.load_golden_scene("cornell_mirror")
+    assert (sc.W, sc.H) == (1920, 1080)
+    tr = make_tracer(sc)
+    tr.set_image(None); tr.render(1, 2)
+    a = tr.image()
+    st = tr.stats()
+    live = [st.live[k] for k in range(9)]
+    assert live[0] == 2 * 1920 * 1080 and all(live[k] >= live[k + 1] for k in range(8)) and live[8] > 0
+    tr.set_image(None); tr.reset_stats(); tr.render(1, 2)
+    assert np.array_equal(a, tr.image())                           # deterministic
+    n, arrs, pix = tr.trace_pool(1, 4)
+    assert n == len(pix) and np.all(np.diff(pix.astype(np.int64)) > 0)
+    assert np.isfinite(a).all() and a.max() > 0
+    # oracle on a thin slice of rows of the same frame (row interleave 135 -> 8 rows), bit-exact
+    sh = make_tracer(sc, row_offset=7, row_stride=135)
+    sh.set_image(None); sh.render(1, 2)
+    want, _ = orc.render(sc, oracle_config(8, row_offset=7, row_stride=135), 1, 2)
+    got = sh.image()
+    assert np.array_equal(got, want)
+    rows = np.arange(1080) % 135 == 7
+    assert np.array_equal(got[rows], a[rows])
