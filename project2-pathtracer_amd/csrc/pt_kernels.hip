@@ -35,7 +35,7 @@ namespace {
 constexpr int kBlock = 256;          // 4 waves
 constexpr int kWaves = kBlock / 64;
 constexpr int kFields = 10;          // ox oy oz dx dy dz tr tg tb pixel
-constexpr uint32_t kSpinLimit = 1u << 24;
+constexpr uint32_t kSpinLimit = 1u << 22;
 
 typedef unsigned long long u64;
 
