@@ -89,10 +89,12 @@ typedef struct {
     int   row_offset;        /* multi-GPU: this context owns rows y with y % row_stride == */
     int   row_stride;        /*   row_offset (single GPU: 0, 1) */
     int   geometry_path;     /* 0 = LDS-staged geometry table (default), 1 = scalar loads */
-    int   chunk_rays;        /* rays per compaction ticket (0 = default) */
+    int   chunk_rays;        /* slots per pool segment / rays per look-back ticket (0 = default) */
     int   blocks_per_cu;     /* persistent grid size = CUs * this (0 = default) */
     int   profile;           /* 1 = bracket every kernel launch with HIP events */
-    int   reserved[7];
+    int   compaction;        /* 0 = wave-autonomous segmented compaction (default)
+                                1 = global decoupled look-back scan (dense pool) */
+    int   reserved[6];
 } pt_config;
 
 typedef struct pt_context pt_context;

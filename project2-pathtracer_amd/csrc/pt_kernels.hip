@@ -63,6 +63,8 @@ struct GenArgs {
     u64 *status;
     uint32_t status_words;
     int depth;
+    uint32_t *seg_cnt0;              // segmented mode: rays per segment entering bounce 0
+    uint32_t nseg, seg_slots;
 };
 
 struct BounceArgs {
@@ -132,6 +134,10 @@ __global__ __launch_bounds__(kBlock) void k_generate(GenArgs a) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     // reset the sync state of this iteration (visible to the bounce kernels at the kernel boundary)
     if (gid < a.status_words) a.status[gid] = 0ull;
+    if (a.seg_cnt0 && gid < a.nseg) {
+        const uint32_t first = gid * a.seg_slots;
+        a.seg_cnt0[gid] = first >= a.n_own ? 0u : (a.n_own - first < a.seg_slots ? a.n_own - first : a.seg_slots);
+    }
     if (blockIdx.x == 0 && threadIdx.x < 72) {
         const uint32_t k = threadIdx.x;
         a.sync->totals[k] += a.sync->counts[k];          // fold the previous iteration (stats)
@@ -152,6 +158,37 @@ __global__ __launch_bounds__(kBlock) void k_generate(GenArgs a) {
     p[3 * cap] = d.x; p[4 * cap] = d.y; p[5 * cap] = d.z;
     p[6 * cap] = 1.0f; p[7 * cap] = 1.0f; p[8 * cap] = 1.0f;
     reinterpret_cast<uint32_t *>(p)[9 * cap] = pixel;
+}
+
+// ------------------------------------------------------------------ one ray, one bounce -
+// nearest hit -> material -> scatter / emit.  Returns true while the path stays alive; o, d, thr
+// are updated in place.  LAST: depth exhausted -- only emitters matter, survivors are counted.
+template <bool GEOM_LDS, bool LAST>
+__device__ __forceinline__ bool bounce_ray(const GeomRec *lg, const GeomRec *__restrict__ geoms, const MatRec *lm,
+                                           int G, int bounce, uint32_t iteration, float *image, uint32_t pixel,
+                                           f3 &o, f3 &d, f3 &thr, uint32_t &emitted) {
+    float t;
+    f3 P, N;
+    int hit;
+    if (GEOM_LDS) hit = nearest_hit(lg, G, o, d, t, P, N);
+    else hit = nearest_hit(geoms, G, o, d, t, P, N);
+    if (hit < 0) return false;
+    const int mid = GEOM_LDS ? lg[hit].mat : geoms[hit].mat;
+    const MatRec m = lm[mid];
+    if (LAST && !(m.emittance > 0.0f)) return true;       // depth exhausted: alive, contributes 0
+    uint32_t st = lcg_seed(stream_seed(pixel, iteration, 1u + (uint32_t)bounce));
+    st = lcg_next(st); const float u_sel = u01(st);
+    st = lcg_next(st); const float xi1 = u01(st);
+    st = lcg_next(st); const float xi2 = u01(st);
+    f3 L = mk(0.0f, 0.0f, 0.0f);
+    const int code = scatter(m, P, N, u_sel, xi1, xi2, o, d, thr, L);
+    if (code == 3) {
+        // exactly one live path per pixel per iteration: plain read-modify-write, no atomics
+        float *px = image + (size_t)pixel * 3;
+        px[0] = px[0] + L.x; px[1] = px[1] + L.y; px[2] = px[2] + L.z;
+        emitted++;
+    }
+    return code <= 2;
 }
 
 // ------------------------------------------------------------------ bounce -------------
@@ -224,32 +261,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(BounceArgs a, const GeomRec *
                 d = mk(p[3 * cap], p[4 * cap], p[5 * cap]);
                 thr = mk(p[6 * cap], p[7 * cap], p[8 * cap]);
                 pixel = reinterpret_cast<const uint32_t *>(p)[9 * cap];
-                float t;
-                f3 P, N;
-                int hit;
-                if (GEOM_LDS) hit = nearest_hit(lg, a.G, o, d, t, P, N);
-                else hit = nearest_hit(geoms, a.G, o, d, t, P, N);
-                if (hit >= 0) {
-                    const int mid = GEOM_LDS ? lg[hit].mat : geoms[hit].mat;
-                    const MatRec m = lm[mid];
-                    if (LAST && !(m.emittance > 0.0f)) {
-                        alive = true;                     // depth exhausted: alive, contributes 0
-                    } else {
-                        uint32_t st = lcg_seed(stream_seed(pixel, a.iteration, 1u + (uint32_t)a.bounce));
-                        st = lcg_next(st); const float u_sel = u01(st);
-                        st = lcg_next(st); const float xi1 = u01(st);
-                        st = lcg_next(st); const float xi2 = u01(st);
-                        f3 L = mk(0.0f, 0.0f, 0.0f);
-                        const int code = scatter(m, P, N, u_sel, xi1, xi2, o, d, thr, L);
-                        if (code == 3) {
-                            // exactly one live path per pixel per iteration: plain read-modify-write
-                            float *px = a.image + (size_t)pixel * 3;
-                            px[0] = px[0] + L.x; px[1] = px[1] + L.y; px[2] = px[2] + L.z;
-                            emitted++;
-                        }
-                        alive = (code <= 2);
-                    }
-                }
+                alive = bounce_ray<GEOM_LDS, LAST>(lg, geoms, lm, a.G, a.bounce, a.iteration, a.image, pixel, o, d, thr, emitted);
             }
             const u64 ballot = __ballot(alive);
             if (LAST) {
@@ -293,6 +305,91 @@ __global__ __launch_bounds__(kBlock) void k_bounce(BounceArgs a, const GeomRec *
     }
     for (int s = 32; s > 0; s >>= 1) emitted += __shfl_down(emitted, s);
     if (lane == 0 && emitted) atomicAdd(&a.sync->emitted, (u64)emitted);
+}
+
+// ------------------------------------------------------------------ bounce, segmented ---
+// Wave-autonomous segmented compaction (the default).  The pool is cut into fixed segments of
+// S = 64*rpt slots; segment s holds cnt_in[s] live rays packed at its start, in generation
+// order.  ONE WAVE owns a segment for the whole launch: it streams the segment 64 rays at a
+// time, and survivors go straight from registers to the same segment of the output pool at
+// base + running + mbcnt(ballot) -- no inter-wave traffic, no barrier, no ticket, no look-back.
+// Global order is still generation order (segments are ordered, each is dense), so the stream
+// stays coherent and the result is bit-identical to the look-back variant.
+struct SegArgs {
+    const float *in;
+    float *out;
+    uint32_t cap;
+    float *image;
+    int G, M;
+    SyncBlock *sync;
+    const uint32_t *cnt_in;          // [nseg]
+    uint32_t *cnt_out;               // [nseg]
+    uint32_t nseg;
+    uint32_t seg_slots;              // S
+    int bounce;
+    uint32_t iteration;
+};
+
+template <bool GEOM_LDS, bool LAST>
+__global__ __launch_bounds__(kBlock) void k_bounce_seg(SegArgs a, const GeomRec *__restrict__ geoms,
+                                                       const MatRec *__restrict__ mats) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t *ctrl = reinterpret_cast<uint32_t *>(smem);   // [0] survivors, [1] emitted (block sums)
+    if (threadIdx.x < 2) ctrl[threadIdx.x] = 0u;
+    GeomRec *lg;
+    MatRec *lm;
+    stage_tables(smem, geoms, a.G, mats, a.M, GEOM_LDS, lg, lm);     // ends with __syncthreads()
+
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t wslot = blockIdx.x * kWaves + wave, nslots = gridDim.x * kWaves;
+    const size_t cap = a.cap;
+    const uint32_t S = a.seg_slots;
+    uint32_t emitted = 0u, survivors = 0u;
+
+    for (uint32_t seg = wslot; seg < a.nseg; seg += nslots) {
+        const uint32_t n = a.cnt_in[seg];
+        const uint32_t base = seg * S;
+        uint32_t running = 0u;
+        for (uint32_t g = 0; g < n; g += 64u) {
+            const uint32_t k = g + lane;
+            bool alive = false;
+            f3 o, d, thr;
+            uint32_t pixel = 0u;
+            if (k < n) {
+                const float *p = a.in + base + k;
+                o = mk(p[0 * cap], p[1 * cap], p[2 * cap]);
+                d = mk(p[3 * cap], p[4 * cap], p[5 * cap]);
+                thr = mk(p[6 * cap], p[7 * cap], p[8 * cap]);
+                pixel = reinterpret_cast<const uint32_t *>(p)[9 * cap];
+                alive = bounce_ray<GEOM_LDS, LAST>(lg, geoms, lm, a.G, a.bounce, a.iteration, a.image, pixel, o, d, thr, emitted);
+            }
+            const u64 ballot = __ballot(alive);
+            if (!LAST && alive) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32),
+                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
+                float *q = a.out + base + running + rank;
+                q[0 * cap] = o.x; q[1 * cap] = o.y; q[2 * cap] = o.z;
+                q[3 * cap] = d.x; q[4 * cap] = d.y; q[5 * cap] = d.z;
+                q[6 * cap] = thr.x; q[7 * cap] = thr.y; q[8 * cap] = thr.z;
+                reinterpret_cast<uint32_t *>(q)[9 * cap] = pixel;
+            }
+            running += (uint32_t)__popcll(ballot);
+        }
+        if (!LAST && lane == 0) a.cnt_out[seg] = running;
+        survivors += running;
+    }
+
+    // stats: wave sums -> block sums in LDS -> one fire-and-forget global atomic per block
+    for (int sft = 32; sft > 0; sft >>= 1) emitted += __shfl_down(emitted, sft);
+    if (lane == 0) {
+        if (survivors) atomicAdd(&ctrl[0], survivors);
+        if (emitted) atomicAdd(&ctrl[1], emitted);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (ctrl[0]) atomicAdd(&a.sync->counts[a.bounce + 1], ctrl[0]);
+        if (ctrl[1]) atomicAdd(&a.sync->emitted, (u64)ctrl[1]);
+    }
 }
 
 // ------------------------------------------------------------------ flat (reference) ---
@@ -402,6 +499,9 @@ struct pt_context {
     SyncBlock *d_sync = nullptr;
     u64 *d_status = nullptr;
     uint32_t max_chunks = 0, rpt = 3, status_words = 0;
+    bool seg_mode = true;            // wave-autonomous segmented compaction (cfg.compaction == 0)
+    uint32_t nseg = 0, seg_slots = 0;
+    uint32_t *d_segcnt[2] = {nullptr, nullptr};
     uchar4 *d_display = nullptr;
     uint32_t lds_bytes = 0;
     int grid_bounce = 0;
@@ -465,6 +565,8 @@ void free_scene_buffers(pt_context *c) {
     if (c->d_mats) (void)hipFree(c->d_mats);
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->d_display) (void)hipFree(c->d_display);
+    for (int i = 0; i < 2; ++i) { if (c->d_segcnt[i]) (void)hipFree(c->d_segcnt[i]); c->d_segcnt[i] = nullptr; }
+    if (c->image == c->image_own) c->image = nullptr;
     c->image_own = nullptr; c->d_geoms = nullptr; c->d_mats = nullptr; c->d_status = nullptr; c->d_display = nullptr;
     c->scene_ready = false;
 }
@@ -483,6 +585,20 @@ int launch_bounce(pt_context *c, const BounceArgs &a, bool last) {
     return last ? launch_bounce_t<false, true>(c, a) : launch_bounce_t<false, false>(c, a);
 }
 
+template <bool LDS, bool LAST>
+int launch_seg_t(pt_context *c, const SegArgs &a) {
+    hipLaunchKernelGGL((k_bounce_seg<LDS, LAST>), dim3(c->grid_bounce), dim3(kBlock), c->lds_bytes, c->stream, a,
+                       (const GeomRec *)c->d_geoms, (const MatRec *)c->d_mats);
+    HIPCHK(hipGetLastError());
+    return PT_OK;
+}
+
+int launch_seg(pt_context *c, const SegArgs &a, bool last) {
+    Scoped s(c, 1);
+    if (c->geom_lds) return last ? launch_seg_t<true, true>(c, a) : launch_seg_t<true, false>(c, a);
+    return last ? launch_seg_t<false, true>(c, a) : launch_seg_t<false, false>(c, a);
+}
+
 // one iteration; stop_after < 0 renders all bounces, otherwise only the first `stop_after`
 // bounces without the LAST variant (parity hook)
 int enqueue_iteration(pt_context *c, uint32_t iteration, int stop_after) {
@@ -491,13 +607,25 @@ int enqueue_iteration(pt_context *c, uint32_t iteration, int stop_after) {
         Scoped s(c, 0);
         GenArgs g;
         g.cam = c->cam; g.pool = c->pool[0]; g.cap = c->cap; g.n_own = c->n_own; g.iteration = iteration;
-        g.sync = c->d_sync; g.status = c->d_status; g.status_words = c->status_words; g.depth = D;
-        const uint32_t work = c->n_own > c->status_words ? c->n_own : c->status_words;
+        g.sync = c->d_sync; g.status = c->d_status; g.status_words = c->seg_mode ? 0u : c->status_words; g.depth = D;
+        g.seg_cnt0 = c->seg_mode ? c->d_segcnt[0] : nullptr; g.nseg = c->nseg; g.seg_slots = c->seg_slots;
+        uint32_t work = c->n_own > g.status_words ? c->n_own : g.status_words;
+        if (c->seg_mode && c->nseg > work) work = c->nseg;
         hipLaunchKernelGGL(k_generate, dim3((work + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, g);
         HIPCHK(hipGetLastError());
     }
     const int nb = stop_after < 0 ? D : stop_after;
-    for (int b = 0; b < nb; ++b) {
+    for (int b = 0; b < nb && c->seg_mode; ++b) {
+        SegArgs a;
+        a.in = c->pool[b & 1]; a.out = c->pool[(b + 1) & 1]; a.cap = c->cap; a.image = c->image;
+        a.G = c->G; a.M = c->M; a.sync = c->d_sync;
+        a.cnt_in = c->d_segcnt[b & 1]; a.cnt_out = c->d_segcnt[(b + 1) & 1];
+        a.nseg = c->nseg; a.seg_slots = c->seg_slots; a.bounce = b; a.iteration = iteration;
+        const bool last = (stop_after < 0) && (b == D - 1);
+        int rc = launch_seg(c, a, last);
+        if (rc) return rc;
+    }
+    for (int b = 0; b < nb && !c->seg_mode; ++b) {
         BounceArgs a;
         a.in = c->pool[b & 1]; a.out = c->pool[(b + 1) & 1]; a.cap = c->cap; a.image = c->image;
         a.G = c->G; a.M = c->M;
@@ -602,56 +730,83 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     const int stride = c->cfg.row_stride, offset = c->cfg.row_offset;
     const int rows = (H - offset + stride - 1) / stride;
     const uint32_t n_own = (uint32_t)rows * (uint32_t)W;
-    const bool realloc = !c->scene_ready || W != c->W || H != c->H || G != c->G || M != c->M;
-    if (realloc) {
-        free_scene_buffers(c);
-        c->W = W; c->H = H; c->G = G; c->M = M;
-        c->n_own = n_own;
-        const uint32_t chunk_rays = kBlock * c->rpt;
-        c->max_chunks = (n_own + chunk_rays - 1) / chunk_rays;
-        c->cap = c->max_chunks * chunk_rays;              // whole chunks: loads never need a tail guard on cap
-        for (int i = 0; i < 2; ++i) HIPCHK(hipMalloc(&c->pool[i], (size_t)c->cap * kFields * sizeof(float)));
-        HIPCHK(hipMalloc(&c->image_own, (size_t)W * H * 3 * sizeof(float)));
-        HIPCHK(hipMemset(c->image_own, 0, (size_t)W * H * 3 * sizeof(float)));
-        if (!c->image) c->image = c->image_own;
-        HIPCHK(hipMalloc(&c->d_geoms, (size_t)G * sizeof(GeomRec)));
-        HIPCHK(hipMalloc(&c->d_mats, (size_t)M * sizeof(MatRec)));
-        c->status_words = (uint32_t)c->cfg.max_depth * c->max_chunks;
-        HIPCHK(hipMalloc(&c->d_status, (size_t)c->status_words * sizeof(u64)));
-        HIPCHK(hipMemset(c->d_status, 0, (size_t)c->status_words * sizeof(u64)));
-        HIPCHK(hipMalloc(&c->d_display, (size_t)W * H * sizeof(uchar4)));
-    }
-    HIPCHK(hipMemcpy(c->d_geoms, g.data(), (size_t)G * sizeof(GeomRec), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(c->d_mats, m.data(), (size_t)M * sizeof(MatRec), hipMemcpyHostToDevice));
-    pth::camera_basis(cam, &c->cfg, &c->cam);
-
-    // LDS budget and persistent grid
+    // Always rebuild the device state: uploads are rare (once per frame), sizes depend on the scene.
+    free_scene_buffers(c);
+    c->W = W; c->H = H; c->G = G; c->M = M;
+    c->n_own = n_own;
+    c->seg_mode = (c->cfg.compaction == 0);
     c->geom_lds = (c->cfg.geometry_path == 0);
+
+    // LDS budget: tables (+ the ray stage of the look-back variant)
     uint32_t tb = tables_bytes(G, M, c->geom_lds);
-    const uint32_t stage_bytes = kBlock * c->rpt * kFields * sizeof(float);
-    if (c->geom_lds && tb + stage_bytes > 160u * 1024u) {   // table too large for LDS next to the stage
+    const uint32_t stage_bytes = c->seg_mode ? 0u : kBlock * c->rpt * kFields * (uint32_t)sizeof(float);
+    if (c->geom_lds && tb + stage_bytes > 160u * 1024u) {   // table too large for LDS: scalar-load path
         c->geom_lds = false;
         tb = tables_bytes(G, M, false);
     }
     c->lds_bytes = tb + stage_bytes;
-    if (c->lds_bytes > 64u * 1024u) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bounce<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bounce<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bounce<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bounce<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    }
+    const void *fns[8] = {
+        reinterpret_cast<const void *>(&k_bounce<true, false>), reinterpret_cast<const void *>(&k_bounce<false, false>),
+        reinterpret_cast<const void *>(&k_bounce<true, true>), reinterpret_cast<const void *>(&k_bounce<false, true>),
+        reinterpret_cast<const void *>(&k_bounce_seg<true, false>), reinterpret_cast<const void *>(&k_bounce_seg<false, false>),
+        reinterpret_cast<const void *>(&k_bounce_seg<true, true>), reinterpret_cast<const void *>(&k_bounce_seg<false, true>)};
+    if (c->lds_bytes > 64u * 1024u)
+        for (const void *fn : fns) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+
+    // persistent grid: CUs x resident blocks per CU
     int per_cu = c->cfg.blocks_per_cu;
     if (per_cu <= 0) {
         int occ = 0;
-        const void *fn = c->geom_lds ? reinterpret_cast<const void *>(&k_bounce<true, false>)
-                                     : reinterpret_cast<const void *>(&k_bounce<false, false>);
+        const void *fn = fns[(c->seg_mode ? 4 : 0) + (c->geom_lds ? 0 : 1)];
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, kBlock, c->lds_bytes) != hipSuccess || occ < 1) occ = 2;
         per_cu = occ;
     }
     int grid = c->n_cu * per_cu;
-    if ((uint32_t)grid > c->max_chunks) grid = (int)c->max_chunks;
+
+    if (c->seg_mode) {
+        // segment size: by default one segment per resident wave (every wave gets equal work in the
+        // first, largest bounce and no second round is needed); cfg.chunk_rays overrides.
+        uint32_t S;
+        if (c->cfg.chunk_rays > 0) S = ((uint32_t)c->cfg.chunk_rays + 63u) & ~63u;
+        else {
+            const uint32_t waves = (uint32_t)grid * kWaves;
+            S = (((n_own + waves - 1) / waves) + 63u) & ~63u;
+        }
+        if (S < 64u) S = 64u;
+        if (S > 4096u) S = 4096u;
+        c->seg_slots = S;
+        c->nseg = (n_own + S - 1) / S;
+        c->cap = c->nseg * S;
+        c->max_chunks = c->nseg;
+        const uint32_t blocks_needed = (c->nseg + kWaves - 1) / kWaves;
+        if ((uint32_t)grid > blocks_needed) grid = (int)blocks_needed;
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(hipMalloc(&c->d_segcnt[i], (size_t)c->nseg * sizeof(uint32_t)));
+            HIPCHK(hipMemset(c->d_segcnt[i], 0, (size_t)c->nseg * sizeof(uint32_t)));
+        }
+        c->status_words = 0;
+    } else {
+        const uint32_t chunk_rays = kBlock * c->rpt;
+        c->max_chunks = (n_own + chunk_rays - 1) / chunk_rays;
+        c->cap = c->max_chunks * chunk_rays;
+        if ((uint32_t)grid > c->max_chunks) grid = (int)c->max_chunks;
+        c->status_words = (uint32_t)c->cfg.max_depth * c->max_chunks;
+        HIPCHK(hipMalloc(&c->d_status, (size_t)c->status_words * sizeof(u64)));
+        HIPCHK(hipMemset(c->d_status, 0, (size_t)c->status_words * sizeof(u64)));
+    }
     if (grid < 1) grid = 1;
     c->grid_bounce = grid;
+
+    for (int i = 0; i < 2; ++i) HIPCHK(hipMalloc(&c->pool[i], (size_t)c->cap * kFields * sizeof(float)));
+    HIPCHK(hipMalloc(&c->image_own, (size_t)W * H * 3 * sizeof(float)));
+    HIPCHK(hipMemset(c->image_own, 0, (size_t)W * H * 3 * sizeof(float)));
+    if (!c->image) c->image = c->image_own;
+    HIPCHK(hipMalloc(&c->d_geoms, (size_t)G * sizeof(GeomRec)));
+    HIPCHK(hipMalloc(&c->d_mats, (size_t)M * sizeof(MatRec)));
+    HIPCHK(hipMalloc(&c->d_display, (size_t)W * H * sizeof(uchar4)));
+    HIPCHK(hipMemcpy(c->d_geoms, g.data(), (size_t)G * sizeof(GeomRec), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_mats, m.data(), (size_t)M * sizeof(MatRec), hipMemcpyHostToDevice));
+    pth::camera_basis(cam, &c->cfg, &c->cam);
     c->scene_ready = true;
     return PT_OK;
 }
@@ -825,9 +980,29 @@ int pt_debug_trace_pool(pt_context *c, int iteration, int bounces, int *count, f
     if (count) *count = (int)n;
     const float *src = c->pool[bounces & 1];
     float *dst[9] = {ox, oy, oz, dx, dy, dz, tr, tg, tb};
-    for (int f = 0; f < 9; ++f)
-        if (dst[f] && n) HIPCHK(hipMemcpy(dst[f], src + (size_t)f * c->cap, (size_t)n * 4, hipMemcpyDeviceToHost));
-    if (pixel && n) HIPCHK(hipMemcpy(pixel, src + (size_t)9 * c->cap, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (!c->seg_mode) {
+        for (int f = 0; f < 9; ++f)
+            if (dst[f] && n) HIPCHK(hipMemcpy(dst[f], src + (size_t)f * c->cap, (size_t)n * 4, hipMemcpyDeviceToHost));
+        if (pixel && n) HIPCHK(hipMemcpy(pixel, src + (size_t)9 * c->cap, (size_t)n * 4, hipMemcpyDeviceToHost));
+    } else if (n) {
+        // segments are dense prefixes in generation order: concatenate them
+        std::vector<uint32_t> cnt(c->nseg);
+        HIPCHK(hipMemcpy(cnt.data(), c->d_segcnt[bounces & 1], (size_t)c->nseg * 4, hipMemcpyDeviceToHost));
+        std::vector<float> field(c->cap);
+        uint64_t total = 0;
+        for (uint32_t sgi = 0; sgi < c->nseg; ++sgi) total += cnt[sgi];
+        if (total != n) { pth::set_error("segment counts (%llu) disagree with the live counter (%u)", (unsigned long long)total, n); return PT_ERR_HIP; }
+        for (int f = 0; f < 10; ++f) {
+            float *out = f < 9 ? dst[f] : reinterpret_cast<float *>(pixel);
+            if (!out) continue;
+            HIPCHK(hipMemcpy(field.data(), src + (size_t)f * c->cap, (size_t)c->cap * 4, hipMemcpyDeviceToHost));
+            size_t w = 0;
+            for (uint32_t sgi = 0; sgi < c->nseg; ++sgi) {
+                memcpy(out + w, field.data() + (size_t)sgi * c->seg_slots, (size_t)cnt[sgi] * 4);
+                w += cnt[sgi];
+            }
+        }
+    }
     return check_device_error(c);
 }
 

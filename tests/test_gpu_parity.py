@@ -174,7 +174,8 @@ def test_accumulation_continues_from_host_image(pt, cornell200):
     assert np.array_equal(a, want)
 
 
-@pytest.mark.parametrize("kw", [dict(geometry_path=1), dict(chunk_rays=256), dict(chunk_rays=1024), dict(blocks_per_cu=1)])
+@pytest.mark.parametrize("kw", [dict(geometry_path=1), dict(chunk_rays=64), dict(chunk_rays=256), dict(chunk_rays=1000), dict(blocks_per_cu=1),
+                                dict(compaction=1), dict(compaction=1, chunk_rays=256), dict(compaction=1, chunk_rays=1024, geometry_path=1)])
 def test_launch_variants_are_bit_identical(pt, cornell200, kw):
     ref = make_tracer(cornell200)
     ref.set_image(None); ref.render(1, 3)
