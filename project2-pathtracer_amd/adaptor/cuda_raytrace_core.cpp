@@ -1,0 +1,137 @@
+// cuda_raytrace_core.cpp -- the ONE symbol the reference's host code calls on the hot path,
+//
+//     void cudaRaytraceCore(uchar4* pos, camera* renderCam, int frame, int iterations,
+//                           material* materials, int numberOfMaterials,
+//                           geom* geoms, int numberOfGeoms);
+//
+// (declared /root/reference/src/raytraceKernel.h:18, defined src/raytraceKernel.cu:164-227, only
+// caller src/main.cpp:126), re-implemented on top of the C ABI of libptmi355.so.
+//
+// Build this TU with the SAME compiler, C++ runtime and headers as the reference's main.cpp and
+// scene.cpp: it includes the reference's own sceneStructs.h (so `camera`, which embeds a
+// std::string, `geom`, `material` and `uchar4` are the caller's types and the mangled name
+// matches), and it crosses into the HIP library only through include/ptmi355.h (PODs, no HIP
+// headers here).  See INTEGRATION.md.
+//
+// Semantics kept from the reference wrapper:
+//   * `iterations` is the 1-based index of this call (main.cpp:110) and seeds the sample;
+//   * renderCam->image is in/out: it is uploaded when a frame starts (iterations == 1: main.cpp
+//     zeroes it between frames, :168-170) and holds the SUM over iterations when main.cpp reads
+//     it (:136-147) -- downloaded on the final iteration, or every call with PT_SYNC_EVERY_CALL=1;
+//   * `pos` receives sendImageToPBO's bytes (raytraceKernel.cu:88-119) when non-NULL;
+//   * errors print "Cuda error: <what>: <why>." and exit(EXIT_FAILURE) (raytraceKernel.cu:20-26).
+// Options the reference has no channel for come from the environment:
+//   PT_MODE=pathtrace|reference  PT_MAX_DEPTH  PT_CAMERA_MODE  PT_AA  PT_APERTURE  PT_FOCAL_DIST
+//   PT_DEVICE  PT_PBO_IS_DEVICE  PT_SYNC_EVERY_CALL
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "sceneStructs.h"   // the reference's header (-I<reference>/src)
+#include "ptmi355.h"
+
+static_assert(sizeof(material) == sizeof(pt_material), "material layout differs from pt_material");
+static_assert(sizeof(cudaMat4) == 64, "cudaMat4 must be four rows of four floats");
+
+namespace {
+
+pt_context *g_ctx = nullptr;
+unsigned long long g_scene_hash = 0;
+int g_mode = 0;
+
+[[noreturn]] void die(const char *what) {
+    fprintf(stderr, "Cuda error: %s: %s.\n", what, pt_last_error());
+    exit(EXIT_FAILURE);
+}
+
+int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+float env_float(const char *name, float dflt) {
+    const char *v = getenv(name);
+    return (v && *v) ? (float)atof(v) : dflt;
+}
+
+unsigned long long fnv1a(const void *p, size_t n, unsigned long long h) {
+    const unsigned char *b = static_cast<const unsigned char *>(p);
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+void rows3(const cudaMat4 &m, float out[12]) {
+    const glm::vec4 r[3] = {m.x, m.y, m.z};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j) out[4 * i + j] = r[i][j];
+}
+
+}  // namespace
+
+// the shim's cudaDeviceReset() (main.cpp:159,171) should call this: drops all device state
+extern "C" void ptmi355_adaptor_reset(void) {
+    if (g_ctx) pt_destroy(g_ctx);
+    g_ctx = nullptr;
+    g_scene_hash = 0;
+}
+
+void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iterations, material *materials,
+                      int numberOfMaterials, geom *geoms, int numberOfGeoms) {
+    if (!g_ctx) {
+        pt_config cfg;
+        pt_config_default(&cfg);
+        const char *mode = getenv("PT_MODE");
+        g_mode = (mode && !strcmp(mode, "reference")) ? 1 : 0;
+        cfg.mode = g_mode;
+        cfg.device = env_int("PT_DEVICE", 0);
+        cfg.max_depth = env_int("PT_MAX_DEPTH", 8);
+        cfg.camera_mode = env_int("PT_CAMERA_MODE", 0);
+        cfg.antialias = env_int("PT_AA", 0);
+        cfg.aperture = env_float("PT_APERTURE", 0.0f);
+        cfg.focal_distance = env_float("PT_FOCAL_DIST", 0.0f);
+        if (pt_create(&cfg, &g_ctx) != PT_OK) die("pt_create");
+    }
+
+    // pack the frame exactly as the reference wrapper does (raytraceKernel.cu:179-206)
+    std::vector<pt_geom> pg(numberOfGeoms);
+    for (int i = 0; i < numberOfGeoms; ++i) {
+        pg[i].type = (int)geoms[i].type;
+        pg[i].materialid = geoms[i].materialid;
+        rows3(geoms[i].transforms[frame], pg[i].transform);
+        rows3(geoms[i].inverseTransforms[frame], pg[i].inverseTransform);
+    }
+    pt_camera cam;
+    cam.resolution[0] = renderCam->resolution.x; cam.resolution[1] = renderCam->resolution.y;
+    for (int k = 0; k < 3; ++k) {
+        cam.position[k] = renderCam->positions[frame][k];
+        cam.view[k] = renderCam->views[frame][k];
+        cam.up[k] = renderCam->ups[frame][k];
+    }
+    cam.fov[0] = renderCam->fov.x; cam.fov[1] = renderCam->fov.y;
+
+    // the caller re-allocates geoms/materials every call (main.cpp:114-122): key the device copy
+    // on CONTENT, never on the pointers
+    unsigned long long h = fnv1a(pg.data(), pg.size() * sizeof(pt_geom), 1469598103934665603ull);
+    h = fnv1a(materials, (size_t)numberOfMaterials * sizeof(material), h);
+    h = fnv1a(&cam, sizeof cam, h);
+    if (h != g_scene_hash) {
+        if (pt_upload_scene(g_ctx, pg.data(), numberOfGeoms, reinterpret_cast<const pt_material *>(materials),
+                            numberOfMaterials, &cam) != PT_OK) die("pt_upload_scene");
+        g_scene_hash = h;
+        if (pt_set_image(g_ctx, reinterpret_cast<const float *>(renderCam->image)) != PT_OK) die("pt_set_image");
+    } else if (iterations == 1) {
+        if (pt_set_image(g_ctx, reinterpret_cast<const float *>(renderCam->image)) != PT_OK) die("pt_set_image");
+    }
+
+    if (pt_render(g_ctx, iterations, 1) != PT_OK) die("pt_render");
+
+    if (PBOpos) {
+        const float scale = g_mode == 1 ? 1.0f : 1.0f / (float)iterations;
+        if (pt_display(g_ctx, scale, PBOpos, env_int("PT_PBO_IS_DEVICE", 0)) != PT_OK) die("pt_display");
+    }
+    const bool final_call = (unsigned)iterations >= renderCam->iterations;
+    if (final_call || g_mode == 1 || env_int("PT_SYNC_EVERY_CALL", 0)) {
+        if (pt_get_image(g_ctx, reinterpret_cast<float *>(renderCam->image)) != PT_OK) die("Kernel failed!");
+    }
+}

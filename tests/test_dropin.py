@@ -1,0 +1,102 @@
+"""The drop-in boundary: the reference's OWN host code (scene.cpp, utilities.cpp, image.cpp compiled
+from /root/reference where they lie) driving the HIP library through the adaptor's
+`cudaRaytraceCore` symbol.  oracle/_ref/dropin_driver is built in the container by oracle/Makefile
+and travels to the GPU box as a binary (the reference sources do not)."""
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import orc
+from conftest import ROOT, has_reference, load_package
+
+DRIVER = os.path.join(ROOT, "oracle", "_ref", "dropin_driver")
+K = json.load(open(os.path.join(orc.GOLD, "survey_kats.json")))
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "adaptor.o")), reason="oracle/_ref not built")
+def test_adaptor_defines_the_reference_symbol():
+    """Same mangled name as the declaration in /root/reference/src/raytraceKernel.h:18 produces in
+    main.cpp (types `uchar4`, `camera`, `material`, `geom` from the reference/CUDA headers)."""
+    out = subprocess.run(["nm", os.path.join(ROOT, "oracle", "_ref", "adaptor.o")], capture_output=True, text=True).stdout
+    assert " T _Z16cudaRaytraceCoreP6uchar4P6cameraiiP8materialiP4geomi" in out
+    assert "ptmi355_adaptor_reset" in out
+
+
+@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref/dropin_driver not built")
+def test_error_convention_without_gpu(tmp_path):
+    pkg = load_package()
+    if pkg.lib().pt_device_count() > 0:
+        pytest.skip("a GPU is present")
+    r = subprocess.run([DRIVER, "scene=" + os.path.join(ROOT, "scenes", "cornell_c1.txt"), "out=" + str(tmp_path)],
+                       capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 1                                        # exit(EXIT_FAILURE)
+    assert r.stderr.startswith("Cuda error: ") and r.stderr.rstrip().endswith(".")   # raytraceKernel.cu:23
+
+
+def _small_scene(tmp_path, w, h, iters):
+    text = open(os.path.join(ROOT, "scenes", "cornell_mirror.txt")).read()
+    text = text.replace("RES         1920 1080", "RES         %d %d" % (w, h)).replace("ITERATIONS  1000", "ITERATIONS  %d" % iters)
+    p = tmp_path / "small.txt"
+    p.write_text(text)
+    return str(p)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref/dropin_driver not built")
+def test_config1_through_reference_host_code(tmp_path):
+    """BASELINE config 1 through the reference's scene parser, the adaptor, the HIP library in
+    reference-kernel mode and the reference's image writer: the saved BMP's raster is the one the
+    unchanged reference produced (sha256 from the survey)."""
+    env = dict(os.environ, PT_MODE="reference")
+    r = subprocess.run([DRIVER, "scene=" + os.path.join(ROOT, "scenes", "cornell_c1.txt"), "frame=0", "out=" + str(tmp_path)],
+                       capture_output=True, text=True, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr
+    bmp = (tmp_path / "sampleScene.0.bmp").read_bytes()
+    assert len(bmp) == K["c1_bmp"]["file_bytes"]
+    rows = [bmp[54 + y * 1200: 54 + (y + 1) * 1200] for y in range(399, -1, -1)]
+    raster = np.frombuffer(b"".join(rows), np.uint8).reshape(400, 400, 3)[:, :, ::-1]
+    assert hashlib.sha256(raster.tobytes()).hexdigest() == K["c1_bmp"]["raster_sha256"]
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref/dropin_driver not built")
+def test_path_trace_through_reference_host_code(tmp_path):
+    pkg = load_package()
+    scene_path = _small_scene(tmp_path, 64, 48, 3)
+    env = dict(os.environ, PT_MODE="pathtrace", PT_MAX_DEPTH="5")
+    r = subprocess.run([DRIVER, "scene=" + scene_path, "out=" + str(tmp_path)], capture_output=True, text=True, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr
+    got = np.fromfile(str(tmp_path / "cornell_mirror.0.bmp.f32"), np.float32).reshape(48, 64, 3)
+    sf = pkg.SceneFile(scene_path)
+    geoms, mats, cam = sf.flatten(0)
+    import ctypes as C
+    sc = orc.Scene([], [], orc.Camera())
+    for g in geoms:
+        og = orc.Geom(); og.type, og.materialid = g.type, g.materialid
+        for k in range(12):
+            og.transform[k] = g.transform[k]; og.inverseTransform[k] = g.inverseTransform[k]
+        og.transform[15] = og.inverseTransform[15] = 1.0
+        sc.geoms.append(og)
+    for m in mats:
+        om = orc.Material(); C.memmove(C.byref(om), C.byref(m), 64); sc.materials.append(om)
+    C.memmove(C.byref(sc.camera), C.byref(cam), 52)
+    want, _ = orc.render(sc, orc.default_config(5), 1, 3)
+    assert np.array_equal(got, want)
+    # the saved file = gamma/clamp/u8 of that sum with divisor = iterations, through the reference's image class
+    ref_u8 = np.zeros(48 * 64 * 3, np.uint8)
+    orc.lib().orc_image_to_u8(orc.fptr(want), 48 * 64, 3.0, float(np.float32(1 / 2.2)), ref_u8.ctypes.data_as(C.POINTER(C.c_uint8)))
+    bmp = (tmp_path / "cornell_mirror.0.bmp").read_bytes()
+    rows = [bmp[54 + y * 192: 54 + (y + 1) * 192] for y in range(47, -1, -1)]
+    assert np.array_equal(np.frombuffer(b"".join(rows), np.uint8).reshape(48, 64, 3)[:, :, ::-1].reshape(-1), ref_u8)
+    # the PBO bytes of the last call: sendImageToPBO of sum/iterations
+    pbo = np.fromfile(str(tmp_path / "cornell_mirror.0.bmp.pbo"), np.uint8).reshape(-1, 4)
+    o = (C.c_uint8 * 4)()
+    scale = np.float32(1.0) / np.float32(3)
+    for idx in (0, 1000, 3071):
+        px = (want.reshape(-1, 3)[idx] * scale).astype(np.float32)
+        orc.lib().orc_display_pixel(orc.vec3(*px), o)
+        assert list(pbo[idx]) == list(o)

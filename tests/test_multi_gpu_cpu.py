@@ -1,0 +1,42 @@
+"""N>1 path on CPU: world_size-2 (and 3) gloo runs of the row-sharded render + reduce."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_sharded_reduce_is_bit_identical(tmp_path, world):
+    port = _free_port()
+    out = tmp_path / "result.txt"
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(out)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        o, _ = p.communicate(timeout=240)
+        logs.append(o.decode(errors="replace"))
+        assert p.returncode == 0, logs[-1][-2000:]
+    assert out.read_text() == "OK", logs
+
+
+def test_bench_rejects_mismatched_world_size():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "torch.distributed.run" in (r.stderr + r.stdout)
