@@ -94,7 +94,9 @@ typedef struct {
     int   profile;           /* 1 = bracket every kernel launch with HIP events */
     int   compaction;        /* 0 = wave-autonomous segmented compaction (default)
                                 1 = global decoupled look-back scan (dense pool) */
-    int   reserved[6];
+    int   culling;           /* 0 = conservative AABB candidate culling before the exact tests (default;
+                                results identical), 1 = brute force over all primitives */
+    int   reserved[5];
 } pt_config;
 
 typedef struct pt_context pt_context;

@@ -90,14 +90,18 @@ __device__ __forceinline__ void sincos_poly(float a, float &s, float &c) {
 // ---------------------------------------------------------------- tables ---------------
 // One primitive as the kernels read it: rows x,y,z of inverseTransform and transform
 // (multiplyMV never reads row w, src/intersections.h:53-59), 28 dwords = 112 B so that every
-// row is a 16-byte LDS read.
-struct GeomRec {
+// row is a 16-byte LDS read; + the culling box: 36 dwords = 144 B (a stride that keeps the
+// per-lane gathers of up to 9 different primitives bank-conflict free).
+struct __attribute__((aligned(16))) GeomRec {
     float inv[12];
     float xf[12];
     int type;
     int mat;
     int inside_hits;   // box only: material is refractive (build extension)
-    int pad;
+    float slack;       // world-space slack subtracted from the AABB entry distance before it is
+                       // compared with the best hit (sphere: the 1e-4 object-space pull-back, scaled)
+    float bmin[4];     // conservative world-space AABB (inflated), xyz + pad
+    float bmax[4];
 };
 // material fields the scatter reads (src/sceneStructs.h:62-73), 12 dwords
 struct MatRec {

@@ -101,6 +101,84 @@ __device__ __forceinline__ int nearest_hit(GeomPtr geoms, int G, f3 o, f3 d, flo
     return hit;
 }
 
+// ------------------------------------------------------------------ nearest hit, culled -
+// Same RESULT as nearest_hit (the reference loop), fewer instructions: (A) a wave-uniform pass
+// tests the ray against every primitive's conservative world-space AABB (approximate
+// reciprocals, margins on both sides) and leaves a per-lane candidate mask; (B) each lane runs
+// the EXACT reference test only on its own candidates, fetching that primitive's matrices with a
+// per-lane index (this is what the LDS staging is for: 64 lanes read up to 64 different
+// primitives per instruction) -- boxes first, then spheres, so that the two code paths do not
+// diverge inside a wave.  A candidate whose box is entered farther than the best exact hit so far
+// is skipped.  Nothing is culled that the exact test could report nearer than the winner, and ties
+// go to the lower index exactly like the in-order reference loop (`depth < MAX_DEPTH`, first wins).
+__device__ __forceinline__ float guarded_rcp(float x) {
+    const float ax = fabsf(x);
+    const float g = ax < 1e-30f ? copysignf(1e-30f, x) : x;
+    return __builtin_amdgcn_rcpf(g);
+}
+
+__device__ __forceinline__ void slab(const float *bmin, const float *bmax, f3 o, f3 inv, float &tn, float &tf) {
+    const float ax = (bmin[0] - o.x) * inv.x, bx = (bmax[0] - o.x) * inv.x;
+    const float ay = (bmin[1] - o.y) * inv.y, by = (bmax[1] - o.y) * inv.y;
+    const float az = (bmin[2] - o.z) * inv.z, bz = (bmax[2] - o.z) * inv.z;
+    tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+}
+
+// conservative: entry shrunk, exit grown; NaNs (0*inf cannot occur: reciprocals are finite) aside,
+// a comparison that is false keeps the candidate
+__device__ __forceinline__ bool slab_rejects(float tn, float tf) {
+    const float tnm = tn - (fabsf(tn) * 1e-5f + 1e-5f);
+    const float tfp = tf + (fabsf(tf) * 1e-5f + 1e-5f);
+    return (tnm > tfp) || (tfp < 0.0f);
+}
+
+template <bool GEOM_LDS>
+__device__ __forceinline__ int nearest_hit_culled(const GeomRec *lg, const GeomRec *__restrict__ gg, int G, f3 o, f3 d,
+                                                  float &tbest, f3 &P, f3 &N) {
+    const GeomRec *tab = GEOM_LDS ? lg : gg;
+    const f3 inv = mk(guarded_rcp(d.x), guarded_rcp(d.y), guarded_rcp(d.z));
+    float best = 100000000000000000.0f;
+    int hit = -1;
+    for (int base = 0; base < G; base += 32) {
+        const int n = (G - base) < 32 ? (G - base) : 32;
+        uint32_t mask = 0u, boxbits = 0u, sphbits = 0u;
+        for (int j = 0; j < n; ++j) {                     // wave-uniform index: broadcast / scalar loads
+            const GeomRec &g = tab[base + j];
+            const int type = g.type;
+            if (type == 1) boxbits |= 1u << j;
+            else if (type == 0) sphbits |= 1u << j;
+            else continue;                                // MESH: empty branch in the reference
+            float tn, tf;
+            slab(g.bmin, g.bmax, o, inv, tn, tf);
+            if (!slab_rejects(tn, tf)) mask |= 1u << j;
+        }
+        for (int pass = 0; pass < 2; ++pass) {
+            uint32_t m = mask & (pass == 0 ? boxbits : sphbits);
+            while (m) {                                   // per-lane loop; the wave runs until all lanes are done
+                const int j = __builtin_ctz(m);
+                m &= m - 1u;
+                const GeomRec *g = tab + base + j;        // per-lane gather
+                if (hit >= 0) {
+                    float tn, tf;
+                    slab(g->bmin, g->bmax, o, inv, tn, tf);
+                    const float tnm = tn - (fabsf(tn) * 1e-5f + 1e-5f) - g->slack;
+                    if (tnm > best) continue;             // cannot beat (or tie) the current winner
+                }
+                f3 p, nn;
+                const float depth = pass == 0 ? box_test(g->inv, g->xf, g->inside_hits, o, d, p, nn)
+                                              : sphere_test(g->inv, g->xf, o, d, p, nn);
+                const int idx = base + j;
+                if (depth > -PT_EPSILON && (depth < best || (depth == best && idx < hit))) {
+                    best = depth; hit = idx; P = p; N = nn;
+                }
+            }
+        }
+    }
+    tbest = best;
+    return hit;
+}
+
 // Dynamic LDS layout (all scratch lives in the dynamic region so that its base stays 16-byte
 // aligned): [0,64) control words | material table | geometry table (LDS path) | ray stage.
 constexpr uint32_t kCtrlBytes = 64;
@@ -163,14 +241,15 @@ __global__ __launch_bounds__(kBlock) void k_generate(GenArgs a) {
 // ------------------------------------------------------------------ one ray, one bounce -
 // nearest hit -> material -> scatter / emit.  Returns true while the path stays alive; o, d, thr
 // are updated in place.  LAST: depth exhausted -- only emitters matter, survivors are counted.
-template <bool GEOM_LDS, bool LAST>
+template <bool GEOM_LDS, bool LAST, bool CULL>
 __device__ __forceinline__ bool bounce_ray(const GeomRec *lg, const GeomRec *__restrict__ geoms, const MatRec *lm,
                                            int G, int bounce, uint32_t iteration, float *image, uint32_t pixel,
                                            f3 &o, f3 &d, f3 &thr, uint32_t &emitted) {
     float t;
     f3 P, N;
     int hit;
-    if (GEOM_LDS) hit = nearest_hit(lg, G, o, d, t, P, N);
+    if (CULL) hit = nearest_hit_culled<GEOM_LDS>(lg, geoms, G, o, d, t, P, N);
+    else if (GEOM_LDS) hit = nearest_hit(lg, G, o, d, t, P, N);
     else hit = nearest_hit(geoms, G, o, d, t, P, N);
     if (hit < 0) return false;
     const int mid = GEOM_LDS ? lg[hit].mat : geoms[hit].mat;
@@ -261,7 +340,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(BounceArgs a, const GeomRec *
                 d = mk(p[3 * cap], p[4 * cap], p[5 * cap]);
                 thr = mk(p[6 * cap], p[7 * cap], p[8 * cap]);
                 pixel = reinterpret_cast<const uint32_t *>(p)[9 * cap];
-                alive = bounce_ray<GEOM_LDS, LAST>(lg, geoms, lm, a.G, a.bounce, a.iteration, a.image, pixel, o, d, thr, emitted);
+                alive = bounce_ray<GEOM_LDS, LAST, false>(lg, geoms, lm, a.G, a.bounce, a.iteration, a.image, pixel, o, d, thr, emitted);
             }
             const u64 ballot = __ballot(alive);
             if (LAST) {
@@ -330,7 +409,7 @@ struct SegArgs {
     uint32_t iteration;
 };
 
-template <bool GEOM_LDS, bool LAST>
+template <bool GEOM_LDS, bool LAST, bool CULL>
 __global__ __launch_bounds__(kBlock) void k_bounce_seg(SegArgs a, const GeomRec *__restrict__ geoms,
                                                        const MatRec *__restrict__ mats) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -361,7 +440,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce_seg(SegArgs a, const GeomRec 
                 d = mk(p[3 * cap], p[4 * cap], p[5 * cap]);
                 thr = mk(p[6 * cap], p[7 * cap], p[8 * cap]);
                 pixel = reinterpret_cast<const uint32_t *>(p)[9 * cap];
-                alive = bounce_ray<GEOM_LDS, LAST>(lg, geoms, lm, a.G, a.bounce, a.iteration, a.image, pixel, o, d, thr, emitted);
+                alive = bounce_ray<GEOM_LDS, LAST, CULL>(lg, geoms, lm, a.G, a.bounce, a.iteration, a.image, pixel, o, d, thr, emitted);
             }
             const u64 ballot = __ballot(alive);
             if (!LAST && alive) {
@@ -500,6 +579,7 @@ struct pt_context {
     u64 *d_status = nullptr;
     uint32_t max_chunks = 0, rpt = 3, status_words = 0;
     bool seg_mode = true;            // wave-autonomous segmented compaction (cfg.compaction == 0)
+    bool cull = true;                // AABB candidate culling in front of the exact tests (cfg.culling == 0)
     uint32_t nseg = 0, seg_slots = 0;
     uint32_t *d_segcnt[2] = {nullptr, nullptr};
     uchar4 *d_display = nullptr;
@@ -571,6 +651,33 @@ void free_scene_buffers(pt_context *c) {
     c->scene_ready = false;
 }
 
+// Conservative world-space AABB of a primitive for the culling pass (double precision, then
+// inflated).  Box: the 8 transformed corners of [-.5,.5]^3.  Sphere (an ellipsoid after the affine
+// map): centre +- 0.5*|row_k of the linear part|.  The inflation has to stay below RAY_BIAS_AMOUNT
+// (2e-4) at scene scale, or every scattered ray would keep the wall it just left as a candidate;
+// it has to exceed the few-ulp slop of the exact object-space tests (about 1e-6 at |x| ~ 10).
+void world_bounds(const pt_geom &src, GeomRec *dst) {
+    double lo[3], hi[3], maxabs = 0.0, maxrow = 0.0;
+    const float *m = src.transform;
+    for (int k = 0; k < 3; ++k) {
+        const double a = m[4 * k], b = m[4 * k + 1], c3 = m[4 * k + 2], t = m[4 * k + 3];
+        double ext;
+        if (src.type == 0) ext = 0.5 * std::sqrt(a * a + b * b + c3 * c3);
+        else ext = 0.5 * (std::fabs(a) + std::fabs(b) + std::fabs(c3));
+        lo[k] = t - ext; hi[k] = t + ext;
+        maxabs = std::fmax(maxabs, std::fmax(std::fabs(lo[k]), std::fabs(hi[k])));
+        maxrow = std::fmax(maxrow, std::sqrt(a * a + b * b + c3 * c3));
+    }
+    const double infl = 3e-5 + 4e-6 * maxabs;
+    for (int k = 0; k < 3; ++k) {
+        dst->bmin[k] = std::nextafterf((float)(lo[k] - infl), -INFINITY);
+        dst->bmax[k] = std::nextafterf((float)(hi[k] + infl), INFINITY);
+    }
+    dst->bmin[3] = dst->bmax[3] = 0.0f;
+    // the sphere test reports the point 1e-4 (object space, along the ray) in front of the surface
+    dst->slack = src.type == 0 ? (float)(1.5e-4 * maxrow + 1e-5) : 1e-5f;
+}
+
 template <bool LDS, bool LAST>
 int launch_bounce_t(pt_context *c, const BounceArgs &a) {
     hipLaunchKernelGGL((k_bounce<LDS, LAST>), dim3(c->grid_bounce), dim3(kBlock), c->lds_bytes, c->stream, a,
@@ -585,9 +692,9 @@ int launch_bounce(pt_context *c, const BounceArgs &a, bool last) {
     return last ? launch_bounce_t<false, true>(c, a) : launch_bounce_t<false, false>(c, a);
 }
 
-template <bool LDS, bool LAST>
+template <bool LDS, bool LAST, bool CULL>
 int launch_seg_t(pt_context *c, const SegArgs &a) {
-    hipLaunchKernelGGL((k_bounce_seg<LDS, LAST>), dim3(c->grid_bounce), dim3(kBlock), c->lds_bytes, c->stream, a,
+    hipLaunchKernelGGL((k_bounce_seg<LDS, LAST, CULL>), dim3(c->grid_bounce), dim3(kBlock), c->lds_bytes, c->stream, a,
                        (const GeomRec *)c->d_geoms, (const MatRec *)c->d_mats);
     HIPCHK(hipGetLastError());
     return PT_OK;
@@ -595,8 +702,12 @@ int launch_seg_t(pt_context *c, const SegArgs &a) {
 
 int launch_seg(pt_context *c, const SegArgs &a, bool last) {
     Scoped s(c, 1);
-    if (c->geom_lds) return last ? launch_seg_t<true, true>(c, a) : launch_seg_t<true, false>(c, a);
-    return last ? launch_seg_t<false, true>(c, a) : launch_seg_t<false, false>(c, a);
+    if (c->cull) {
+        if (c->geom_lds) return last ? launch_seg_t<true, true, true>(c, a) : launch_seg_t<true, false, true>(c, a);
+        return last ? launch_seg_t<false, true, true>(c, a) : launch_seg_t<false, false, true>(c, a);
+    }
+    if (c->geom_lds) return last ? launch_seg_t<true, true, false>(c, a) : launch_seg_t<true, false, false>(c, a);
+    return last ? launch_seg_t<false, true, false>(c, a) : launch_seg_t<false, false, false>(c, a);
 }
 
 // one iteration; stop_after < 0 renders all bounces, otherwise only the first `stop_after`
@@ -725,7 +836,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         g[i].type = geoms[i].type;
         g[i].mat = geoms[i].materialid;
         g[i].inside_hits = mats[geoms[i].materialid].hasRefractive > 0.0f ? 1 : 0;
-        g[i].pad = 0;
+        world_bounds(geoms[i], &g[i]);
     }
     const int stride = c->cfg.row_stride, offset = c->cfg.row_offset;
     const int rows = (H - offset + stride - 1) / stride;
@@ -735,6 +846,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     c->W = W; c->H = H; c->G = G; c->M = M;
     c->n_own = n_own;
     c->seg_mode = (c->cfg.compaction == 0);
+    c->cull = (c->cfg.culling == 0) && c->seg_mode;
     c->geom_lds = (c->cfg.geometry_path == 0);
 
     // LDS budget: tables (+ the ray stage of the look-back variant)
@@ -748,8 +860,10 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     const void *fns[8] = {
         reinterpret_cast<const void *>(&k_bounce<true, false>), reinterpret_cast<const void *>(&k_bounce<false, false>),
         reinterpret_cast<const void *>(&k_bounce<true, true>), reinterpret_cast<const void *>(&k_bounce<false, true>),
-        reinterpret_cast<const void *>(&k_bounce_seg<true, false>), reinterpret_cast<const void *>(&k_bounce_seg<false, false>),
-        reinterpret_cast<const void *>(&k_bounce_seg<true, true>), reinterpret_cast<const void *>(&k_bounce_seg<false, true>)};
+        reinterpret_cast<const void *>(c->cull ? &k_bounce_seg<true, false, true> : &k_bounce_seg<true, false, false>),
+        reinterpret_cast<const void *>(c->cull ? &k_bounce_seg<false, false, true> : &k_bounce_seg<false, false, false>),
+        reinterpret_cast<const void *>(c->cull ? &k_bounce_seg<true, true, true> : &k_bounce_seg<true, true, false>),
+        reinterpret_cast<const void *>(c->cull ? &k_bounce_seg<false, true, true> : &k_bounce_seg<false, true, false>)};
     if (c->lds_bytes > 64u * 1024u)
         for (const void *fn : fns) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 

@@ -145,7 +145,7 @@ def test_ray_pool_bit_exact_after_k_bounces(pt, cornell200, bounces):
         assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("scene_name,depth,iters", [("sampleScene", 8, 6), ("cornell_mirror", 8, 4), ("cornell_glass_4k", 12, 4)])
+@pytest.mark.parametrize("scene_name,depth,iters", [("sampleScene", 8, 6), ("cornell_mirror", 8, 4), ("cornell_glass_4k", 12, 4), ("random256", 8, 3)])
 def test_image_and_live_counts_match_oracle(pt, scene_name, depth, iters):
     sc = orc.load_golden_scene(scene_name).with_resolution(160, 120)
     tr = make_tracer(sc, depth=depth)
@@ -175,7 +175,7 @@ def test_accumulation_continues_from_host_image(pt, cornell200):
 
 
 @pytest.mark.parametrize("kw", [dict(geometry_path=1), dict(chunk_rays=64), dict(chunk_rays=256), dict(chunk_rays=1000), dict(blocks_per_cu=1),
-                                dict(compaction=1), dict(compaction=1, chunk_rays=256), dict(compaction=1, chunk_rays=1024, geometry_path=1)])
+                                dict(culling=1), dict(culling=1, geometry_path=1), dict(compaction=1), dict(compaction=1, chunk_rays=256), dict(compaction=1, chunk_rays=1024, geometry_path=1)])
 def test_launch_variants_are_bit_identical(pt, cornell200, kw):
     ref = make_tracer(cornell200)
     ref.set_image(None); ref.render(1, 3)
@@ -262,3 +262,19 @@ def test_full_size_properties_1080p(pt):
     assert np.array_equal(got, want)
     rows = np.arange(1080) % 135 == 7
     assert np.array_equal(got[rows], a[rows])
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(geometry_path=1), dict(culling=1)])
+def test_many_primitives_scene_matches_oracle(pt, kw):
+    """BASELINE config 4's scene (256 spheres+cubes incl. rotated cubes, mirrors, glass): the
+    candidate culling must never change the nearest hit."""
+    sc = orc.load_golden_scene("random256").with_resolution(192, 108)
+    tr = make_tracer(sc, depth=8, **kw)
+    tr.set_image(None); tr.render(1, 2)
+    want, live = orc.render(sc, oracle_config(8), 1, 2)
+    st = tr.stats()
+    assert [st.live[k] for k in range(9)] == [int(v) for v in live]
+    assert np.array_equal(tr.image(), want)
+    n, arrs, pix = tr.trace_pool(2, 3)
+    on, oarrs, opix = orc.trace_pool(sc, oracle_config(8), 2, 3)
+    assert n == on and np.array_equal(pix, opix) and all(np.array_equal(a, b) for a, b in zip(arrs, oarrs))
