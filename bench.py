@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--geometry-path", type=int, default=0)
     ap.add_argument("--chunk-rays", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--merge-floor", type=int, default=0)
     ap.add_argument("--culling", type=int, default=0, help="0 = AABB candidate culling (default), 1 = brute force")
     ap.add_argument("--compaction", type=int, default=0, help="0 = segmented (default), 1 = look-back scan")
     args = ap.parse_args()
@@ -144,7 +145,7 @@ def main():
 
     tracer = pkg.PathTracer(pkg.default_config(device=device, max_depth=depth, row_offset=rank, row_stride=world,
                                                geometry_path=args.geometry_path, chunk_rays=args.chunk_rays,
-                                               blocks_per_cu=args.blocks_per_cu, culling=args.culling,
+                                               blocks_per_cu=args.blocks_per_cu, culling=args.culling, merge_floor=args.merge_floor,
                                                compaction=args.compaction))
     tracer.upload(geoms, mats, cam)
     accum = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda:%d" % device)

@@ -89,14 +89,16 @@ typedef struct {
     int   row_offset;        /* multi-GPU: this context owns rows y with y % row_stride == */
     int   row_stride;        /*   row_offset (single GPU: 0, 1) */
     int   geometry_path;     /* 0 = LDS-staged geometry table (default), 1 = scalar loads */
-    int   chunk_rays;        /* slots per pool segment / rays per look-back ticket (0 = default) */
+    int   chunk_rays;        /* slots per level-0 pool segment (default 192) / rays per look-back ticket */
     int   blocks_per_cu;     /* persistent grid size = CUs * this (0 = default) */
     int   profile;           /* 1 = bracket every kernel launch with HIP events */
     int   compaction;        /* 0 = wave-autonomous segmented compaction (default)
                                 1 = global decoupled look-back scan (dense pool) */
     int   culling;           /* 0 = conservative AABB candidate culling before the exact tests (default;
                                 results identical), 1 = brute force over all primitives */
-    int   reserved[5];
+    int   merge_floor;       /* segmented mode, optional: a bounce merges neighbouring segments while the
+                                halved segment count stays >= this (0 = never merge, the default) */
+    int   reserved[4];
 } pt_config;
 
 typedef struct pt_context pt_context;

@@ -33,6 +33,9 @@ using namespace ptd;
 namespace {
 
 constexpr int kBlock = 256;          // 4 waves
+#ifndef PT_SEG_WAVES
+#define PT_SEG_WAVES 4               // min waves per SIMD asked of the register allocator for k_bounce_seg
+#endif
 constexpr int kWaves = kBlock / 64;
 constexpr int kFields = 10;          // ox oy oz dx dy dz tr tg tb pixel
 constexpr uint32_t kSpinLimit = 1u << 22;
@@ -45,7 +48,8 @@ constexpr u64 kStateAgg = 1ull << 32;
 constexpr u64 kStatePrefix = 2ull << 32;
 
 struct SyncBlock {                   // device-resident, one per context
-    uint32_t counts[72];             // live rays entering bounce k of the CURRENT iteration
+    uint32_t counts[72];             // live rays entering bounce k of the CURRENT iteration (bank 0)
+    uint32_t counts_b[72];           // bank 1: the fused segmented path alternates banks per iteration
     uint32_t tickets[72];            // chunk tickets per bounce
     u64 totals[72];                  // counts folded over finished iterations
     u64 emitted;                     // paths ended on an emitter
@@ -117,27 +121,51 @@ __device__ __forceinline__ float guarded_rcp(float x) {
     return __builtin_amdgcn_rcpf(g);
 }
 
-__device__ __forceinline__ void slab(const float *bmin, const float *bmax, f3 o, f3 inv, float &tn, float &tf) {
-    const float ax = (bmin[0] - o.x) * inv.x, bx = (bmax[0] - o.x) * inv.x;
-    const float ay = (bmin[1] - o.y) * inv.y, by = (bmax[1] - o.y) * inv.y;
-    const float az = (bmin[2] - o.z) * inv.z, bz = (bmax[2] - o.z) * inv.z;
-    tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-    tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+// Cull-side arithmetic is NOT part of the bit-exact contract (it only decides which exact tests
+// run), so it may use FMAs and approximate reciprocals -- behind explicit margins.
+struct CullRay {
+    f3 o, d, inv, noi;      // origin, direction, guarded 1/d, -(o * inv)
+};
+
+__device__ __forceinline__ CullRay make_cull_ray(f3 o, f3 d) {
+    CullRay r;
+    r.o = o; r.d = d;
+    r.inv = mk(guarded_rcp(d.x), guarded_rcp(d.y), guarded_rcp(d.z));
+    r.noi = mk(-(o.x * r.inv.x), -(o.y * r.inv.y), -(o.z * r.inv.z));
+    return r;
 }
 
-// conservative: entry shrunk, exit grown; NaNs (0*inf cannot occur: reciprocals are finite) aside,
-// a comparison that is false keeps the candidate
-__device__ __forceinline__ bool slab_rejects(float tn, float tf) {
-    const float tnm = tn - (fabsf(tn) * 1e-5f + 1e-5f);
-    const float tfp = tf + (fabsf(tf) * 1e-5f + 1e-5f);
-    return (tnm > tfp) || (tfp < 0.0f);
+// box: slab test against the inflated world AABB; returns false when the ray certainly misses it.
+// tn = conservative entry distance (may be negative).
+__device__ __forceinline__ bool cull_box(const float *bmin, const float *bmax, const CullRay &r, float &tn) {
+    const float ax = __builtin_fmaf(bmin[0], r.inv.x, r.noi.x), bx = __builtin_fmaf(bmax[0], r.inv.x, r.noi.x);
+    const float ay = __builtin_fmaf(bmin[1], r.inv.y, r.noi.y), by = __builtin_fmaf(bmax[1], r.inv.y, r.noi.y);
+    const float az = __builtin_fmaf(bmin[2], r.inv.z, r.noi.z), bz = __builtin_fmaf(bmax[2], r.inv.z, r.noi.z);
+    const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    const float t0m = t0 - __builtin_fmaf(fabsf(t0), 2e-5f, 2e-5f);       // entry shrunk
+    const float t1p = t1 + __builtin_fmaf(fabsf(t1), 2e-5f, 2e-5f);       // exit grown
+    tn = t0m;
+    return !((t0m > t1p) || (t1p < 0.0f));                                // a false comparison keeps it
+}
+
+// sphere: bounding sphere (centre, inflated R^2 in bmin[3], inflated R in bmax[3]).  The margin on
+// the perpendicular distance is relative to |oc|^2 because d is only unit to ~1e-6.
+__device__ __forceinline__ bool cull_sphere(const float *bmin, const float *bmax, const CullRay &r, float &tn) {
+    const f3 oc = mk(bmin[0] - r.o.x, bmin[1] - r.o.y, bmin[2] - r.o.z);
+    const float b = __builtin_fmaf(oc.z, r.d.z, __builtin_fmaf(oc.y, r.d.y, oc.x * r.d.x));
+    const float c2 = __builtin_fmaf(oc.z, oc.z, __builtin_fmaf(oc.y, oc.y, oc.x * oc.x));
+    const float perp2 = __builtin_fmaf(-b, b, c2);
+    const float lim = __builtin_fmaf(c2, 2e-5f, bmin[3]);
+    tn = b - bmax[3] - __builtin_fmaf(fabsf(b), 2e-5f, 2e-5f);
+    return !((perp2 > lim) || (b < 0.0f && c2 > lim));
 }
 
 template <bool GEOM_LDS>
 __device__ __forceinline__ int nearest_hit_culled(const GeomRec *lg, const GeomRec *__restrict__ gg, int G, f3 o, f3 d,
                                                   float &tbest, f3 &P, f3 &N) {
     const GeomRec *tab = GEOM_LDS ? lg : gg;
-    const f3 inv = mk(guarded_rcp(d.x), guarded_rcp(d.y), guarded_rcp(d.z));
+    const CullRay cr = make_cull_ray(o, d);
     float best = 100000000000000000.0f;
     int hit = -1;
     for (int base = 0; base < G; base += 32) {
@@ -146,12 +174,12 @@ __device__ __forceinline__ int nearest_hit_culled(const GeomRec *lg, const GeomR
         for (int j = 0; j < n; ++j) {                     // wave-uniform index: broadcast / scalar loads
             const GeomRec &g = tab[base + j];
             const int type = g.type;
-            if (type == 1) boxbits |= 1u << j;
-            else if (type == 0) sphbits |= 1u << j;
+            float tn;
+            bool keep;
+            if (type == 1) { boxbits |= 1u << j; keep = cull_box(g.bmin, g.bmax, cr, tn); }
+            else if (type == 0) { sphbits |= 1u << j; keep = cull_sphere(g.bmin, g.bmax, cr, tn); }
             else continue;                                // MESH: empty branch in the reference
-            float tn, tf;
-            slab(g.bmin, g.bmax, o, inv, tn, tf);
-            if (!slab_rejects(tn, tf)) mask |= 1u << j;
+            if (keep) mask |= 1u << j;
         }
         for (int pass = 0; pass < 2; ++pass) {
             uint32_t m = mask & (pass == 0 ? boxbits : sphbits);
@@ -159,11 +187,11 @@ __device__ __forceinline__ int nearest_hit_culled(const GeomRec *lg, const GeomR
                 const int j = __builtin_ctz(m);
                 m &= m - 1u;
                 const GeomRec *g = tab + base + j;        // per-lane gather
-                if (hit >= 0) {
-                    float tn, tf;
-                    slab(g->bmin, g->bmax, o, inv, tn, tf);
-                    const float tnm = tn - (fabsf(tn) * 1e-5f + 1e-5f) - g->slack;
-                    if (tnm > best) continue;             // cannot beat (or tie) the current winner
+                if (hit >= 0) {                           // entered farther than the best exact hit: cannot win or tie
+                    float tn;
+                    if (pass == 0) (void)cull_box(g->bmin, g->bmax, cr, tn);
+                    else (void)cull_sphere(g->bmin, g->bmax, cr, tn);
+                    if (tn - g->slack > best) continue;
                 }
                 f3 p, nn;
                 const float depth = pass == 0 ? box_test(g->inv, g->xf, g->inside_hits, o, d, p, nn)
@@ -401,16 +429,20 @@ struct SegArgs {
     float *image;
     int G, M;
     SyncBlock *sync;
-    const uint32_t *cnt_in;          // [nseg]
-    uint32_t *cnt_out;               // [nseg]
-    uint32_t nseg;
-    uint32_t seg_slots;              // S
+    const uint32_t *cnt_in;          // [nseg_in]
+    uint32_t *cnt_out;               // [nseg_out]
+    uint32_t nseg_in, nseg_out;      // nseg_out = merge ? ceil(nseg_in/2) : nseg_in
+    uint32_t seg_slots;              // S of the INPUT level (output level: merge ? 2S : S)
+    uint32_t merge;                  // 1: a wave reads the pair (2j, 2j+1) and writes ONE segment at 2j*S
     int bounce;
     uint32_t iteration;
+    uint32_t n_own;                  // GEN: rays of bounce 0 come from the camera, not from the pool
+    uint32_t bank;                   // counter bank of this iteration (the host alternates 0/1)
+    CamRec cam;
 };
 
-template <bool GEOM_LDS, bool LAST, bool CULL>
-__global__ __launch_bounds__(kBlock) void k_bounce_seg(SegArgs a, const GeomRec *__restrict__ geoms,
+template <bool GEOM_LDS, bool LAST, bool CULL, bool GEN>
+__global__ __launch_bounds__(kBlock, PT_SEG_WAVES) void k_bounce_seg(SegArgs a, const GeomRec *__restrict__ geoms,
                                                        const MatRec *__restrict__ mats) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *ctrl = reinterpret_cast<uint32_t *>(smem);   // [0] survivors, [1] emitted (block sums)
@@ -424,10 +456,32 @@ __global__ __launch_bounds__(kBlock) void k_bounce_seg(SegArgs a, const GeomRec 
     const size_t cap = a.cap;
     const uint32_t S = a.seg_slots;
     uint32_t emitted = 0u, survivors = 0u;
+    // per-iteration counter banks: this iteration adds into bank a.bank; the GEN launch
+    // (first kernel of an iteration, nothing of the previous iteration still runs) folds the other
+    // bank -- the previous iteration's counts -- into the running totals and clears it.
+    uint32_t *bank = a.bank ? a.sync->counts_b : a.sync->counts;
+    if (GEN && blockIdx.x == 0 && threadIdx.x < 72) {
+        uint32_t *other = a.bank ? a.sync->counts : a.sync->counts_b;
+        a.sync->totals[threadIdx.x] += other[threadIdx.x];
+        other[threadIdx.x] = 0u;
+        if (threadIdx.x == 0) bank[0] = a.n_own;
+    }
 
-    for (uint32_t seg = wslot; seg < a.nseg; seg += nslots) {
-        const uint32_t n = a.cnt_in[seg];
-        const uint32_t base = seg * S;
+    for (uint32_t seg = wslot; seg < a.nseg_out; seg += nslots) {
+        // input: one segment, or (merge) the two neighbours 2j and 2j+1 read as ONE list, so that the
+        // wave groups stay full across the seam; output: a dense prefix starting at the first one's base
+        const uint32_t sa = a.merge ? 2u * seg : seg;
+        uint32_t na, nb;
+        if (GEN) {                                        // level-0 segments are full except the last
+            const uint32_t f0 = sa * S, f1 = f0 + S;
+            na = f0 >= a.n_own ? 0u : (a.n_own - f0 < S ? a.n_own - f0 : S);
+            nb = (!a.merge || f1 >= a.n_own) ? 0u : (a.n_own - f1 < S ? a.n_own - f1 : S);
+        } else {
+            na = a.cnt_in[sa];
+            nb = (a.merge && sa + 1u < a.nseg_in) ? a.cnt_in[sa + 1u] : 0u;
+        }
+        const uint32_t n = na + nb;
+        const uint32_t base = sa * S;
         uint32_t running = 0u;
         for (uint32_t g = 0; g < n; g += 64u) {
             const uint32_t k = g + lane;
@@ -435,11 +489,21 @@ __global__ __launch_bounds__(kBlock) void k_bounce_seg(SegArgs a, const GeomRec 
             f3 o, d, thr;
             uint32_t pixel = 0u;
             if (k < n) {
-                const float *p = a.in + base + k;
-                o = mk(p[0 * cap], p[1 * cap], p[2 * cap]);
-                d = mk(p[3 * cap], p[4 * cap], p[5 * cap]);
-                thr = mk(p[6 * cap], p[7 * cap], p[8 * cap]);
-                pixel = reinterpret_cast<const uint32_t *>(p)[9 * cap];
+                if (GEN) {
+                    // k_generate fused: local ray id -> owned pixel (row interleave) -> camera ray
+                    const uint32_t gid = base + (k < na ? k : k - na + S);
+                    const uint32_t W = (uint32_t)a.cam.W;
+                    const uint32_t lr = gid / W, x = gid - lr * W;
+                    pixel = (lr * (uint32_t)a.cam.row_stride + (uint32_t)a.cam.row_offset) * W + x;
+                    camera_ray(a.cam, pixel, a.iteration, o, d);
+                    thr = mk(1.0f, 1.0f, 1.0f);
+                } else {
+                    const float *p = a.in + base + (k < na ? k : k - na + S);
+                    o = mk(p[0 * cap], p[1 * cap], p[2 * cap]);
+                    d = mk(p[3 * cap], p[4 * cap], p[5 * cap]);
+                    thr = mk(p[6 * cap], p[7 * cap], p[8 * cap]);
+                    pixel = reinterpret_cast<const uint32_t *>(p)[9 * cap];
+                }
                 alive = bounce_ray<GEOM_LDS, LAST, CULL>(lg, geoms, lm, a.G, a.bounce, a.iteration, a.image, pixel, o, d, thr, emitted);
             }
             const u64 ballot = __ballot(alive);
@@ -466,7 +530,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce_seg(SegArgs a, const GeomRec 
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (ctrl[0]) atomicAdd(&a.sync->counts[a.bounce + 1], ctrl[0]);
+        if (ctrl[0]) atomicAdd(&bank[a.bounce + 1], ctrl[0]);
         if (ctrl[1]) atomicAdd(&a.sync->emitted, (u64)ctrl[1]);
     }
 }
@@ -580,7 +644,8 @@ struct pt_context {
     uint32_t max_chunks = 0, rpt = 3, status_words = 0;
     bool seg_mode = true;            // wave-autonomous segmented compaction (cfg.compaction == 0)
     bool cull = true;                // AABB candidate culling in front of the exact tests (cfg.culling == 0)
-    uint32_t nseg = 0, seg_slots = 0;
+    uint32_t nseg = 0, seg_slots = 0;     // level 0 (what k_generate fills)
+    uint32_t lvl_slots[66] = {0}, lvl_nseg[66] = {0};   // level entering bounce b
     uint32_t *d_segcnt[2] = {nullptr, nullptr};
     uchar4 *d_display = nullptr;
     uint32_t lds_bytes = 0;
@@ -588,6 +653,7 @@ struct pt_context {
     bool geom_lds = true;
     bool scene_ready = false;
     bool counts_pending = false;
+    uint32_t bank = 0;               // counter bank of the iteration being enqueued (fused segmented path)
     // profiling
     struct Ev { hipEvent_t a, b; int kind; };
     std::vector<Ev> pending;
@@ -669,11 +735,38 @@ void world_bounds(const pt_geom &src, GeomRec *dst) {
         maxrow = std::fmax(maxrow, std::sqrt(a * a + b * b + c3 * c3));
     }
     const double infl = 3e-5 + 4e-6 * maxabs;
-    for (int k = 0; k < 3; ++k) {
-        dst->bmin[k] = std::nextafterf((float)(lo[k] - infl), -INFINITY);
-        dst->bmax[k] = std::nextafterf((float)(hi[k] + infl), INFINITY);
+    if (src.type == 0) {
+        // bounding sphere of the ellipsoid: centre, R = largest semi-axis <= 0.5 * largest row norm...
+        // the exact bound is 0.5 * the largest singular value; 0.5 * Frobenius norm is a safe over-estimate
+        // for non-uniform scales and equals 0.5*s*sqrt(3) only for... keep it tight for the common
+        // uniform case: rows of equal norm and orthogonal -> R = 0.5 * row norm.
+        double fro = 0.0, ortho = 0.0;
+        for (int k = 0; k < 3; ++k)
+            for (int j = 0; j < 3; ++j) fro += (double)m[4 * k + j] * m[4 * k + j];
+        for (int k = 0; k < 3; ++k)
+            for (int l = k + 1; l < 3; ++l) {
+                double dotp = 0.0;
+                for (int j = 0; j < 3; ++j) dotp += (double)m[4 * k + j] * m[4 * l + j];
+                ortho = std::fmax(ortho, std::fabs(dotp));
+            }
+        double r0 = 0.0, r1 = 1e300;
+        for (int k = 0; k < 3; ++k) {
+            const double rn = std::sqrt((double)m[4 * k] * m[4 * k] + (double)m[4 * k + 1] * m[4 * k + 1] + (double)m[4 * k + 2] * m[4 * k + 2]);
+            r0 = std::fmax(r0, rn); r1 = std::fmin(r1, rn);
+        }
+        const bool uniform = (r0 - r1) <= 1e-5 * r0 && ortho <= 1e-5 * r0 * r0;
+        const double R = (uniform ? 0.5 * r0 : 0.5 * std::sqrt(fro)) + infl;
+        dst->bmin[0] = m[3]; dst->bmin[1] = m[7]; dst->bmin[2] = m[11];
+        dst->bmin[3] = std::nextafterf((float)(R * R * (1.0 + 1e-5)), INFINITY);
+        dst->bmax[0] = dst->bmax[1] = dst->bmax[2] = 0.0f;
+        dst->bmax[3] = std::nextafterf((float)R, INFINITY);
+    } else {
+        for (int k = 0; k < 3; ++k) {
+            dst->bmin[k] = std::nextafterf((float)(lo[k] - infl), -INFINITY);
+            dst->bmax[k] = std::nextafterf((float)(hi[k] + infl), INFINITY);
+        }
+        dst->bmin[3] = dst->bmax[3] = 0.0f;
     }
-    dst->bmin[3] = dst->bmax[3] = 0.0f;
     // the sphere test reports the point 1e-4 (object space, along the ray) in front of the surface
     dst->slack = src.type == 0 ? (float)(1.5e-4 * maxrow + 1e-5) : 1e-5f;
 }
@@ -692,29 +785,34 @@ int launch_bounce(pt_context *c, const BounceArgs &a, bool last) {
     return last ? launch_bounce_t<false, true>(c, a) : launch_bounce_t<false, false>(c, a);
 }
 
-template <bool LDS, bool LAST, bool CULL>
+template <bool LDS, bool LAST, bool CULL, bool GEN>
 int launch_seg_t(pt_context *c, const SegArgs &a) {
-    hipLaunchKernelGGL((k_bounce_seg<LDS, LAST, CULL>), dim3(c->grid_bounce), dim3(kBlock), c->lds_bytes, c->stream, a,
+    hipLaunchKernelGGL((k_bounce_seg<LDS, LAST, CULL, GEN>), dim3(c->grid_bounce), dim3(kBlock), c->lds_bytes, c->stream, a,
                        (const GeomRec *)c->d_geoms, (const MatRec *)c->d_mats);
     HIPCHK(hipGetLastError());
     return PT_OK;
 }
 
-int launch_seg(pt_context *c, const SegArgs &a, bool last) {
+template <bool LDS, bool CULL>
+int launch_seg_lc(pt_context *c, const SegArgs &a, bool last, bool gen) {
+    if (gen) return last ? launch_seg_t<LDS, true, CULL, true>(c, a) : launch_seg_t<LDS, false, CULL, true>(c, a);
+    return last ? launch_seg_t<LDS, true, CULL, false>(c, a) : launch_seg_t<LDS, false, CULL, false>(c, a);
+}
+
+int launch_seg(pt_context *c, const SegArgs &a, bool last, bool gen) {
     Scoped s(c, 1);
-    if (c->cull) {
-        if (c->geom_lds) return last ? launch_seg_t<true, true, true>(c, a) : launch_seg_t<true, false, true>(c, a);
-        return last ? launch_seg_t<false, true, true>(c, a) : launch_seg_t<false, false, true>(c, a);
-    }
-    if (c->geom_lds) return last ? launch_seg_t<true, true, false>(c, a) : launch_seg_t<true, false, false>(c, a);
-    return last ? launch_seg_t<false, true, false>(c, a) : launch_seg_t<false, false, false>(c, a);
+    if (c->cull) return c->geom_lds ? launch_seg_lc<true, true>(c, a, last, gen) : launch_seg_lc<false, true>(c, a, last, gen);
+    return c->geom_lds ? launch_seg_lc<true, false>(c, a, last, gen) : launch_seg_lc<false, false>(c, a, last, gen);
 }
 
 // one iteration; stop_after < 0 renders all bounces, otherwise only the first `stop_after`
 // bounces without the LAST variant (parity hook)
 int enqueue_iteration(pt_context *c, uint32_t iteration, int stop_after) {
     const int D = c->cfg.max_depth;
-    {
+    // The segmented path generates camera rays inside its first bounce launch; k_generate runs only
+    // for the look-back variant and for the parity hook that wants the pool before any bounce.
+    const bool fused = c->seg_mode && stop_after != 0;
+    if (!fused) {
         Scoped s(c, 0);
         GenArgs g;
         g.cam = c->cam; g.pool = c->pool[0]; g.cap = c->cap; g.n_own = c->n_own; g.iteration = iteration;
@@ -726,14 +824,17 @@ int enqueue_iteration(pt_context *c, uint32_t iteration, int stop_after) {
         HIPCHK(hipGetLastError());
     }
     const int nb = stop_after < 0 ? D : stop_after;
+    if (fused) c->bank ^= 1u;
     for (int b = 0; b < nb && c->seg_mode; ++b) {
         SegArgs a;
         a.in = c->pool[b & 1]; a.out = c->pool[(b + 1) & 1]; a.cap = c->cap; a.image = c->image;
         a.G = c->G; a.M = c->M; a.sync = c->d_sync;
         a.cnt_in = c->d_segcnt[b & 1]; a.cnt_out = c->d_segcnt[(b + 1) & 1];
-        a.nseg = c->nseg; a.seg_slots = c->seg_slots; a.bounce = b; a.iteration = iteration;
+        a.nseg_in = c->lvl_nseg[b]; a.nseg_out = c->lvl_nseg[b + 1]; a.seg_slots = c->lvl_slots[b];
+        a.merge = c->lvl_slots[b + 1] != c->lvl_slots[b] ? 1u : 0u;
+        a.bounce = b; a.iteration = iteration; a.n_own = c->n_own; a.cam = c->cam; a.bank = c->bank;
         const bool last = (stop_after < 0) && (b == D - 1);
-        int rc = launch_seg(c, a, last);
+        int rc = launch_seg(c, a, last, b == 0);
         if (rc) return rc;
     }
     for (int b = 0; b < nb && !c->seg_mode; ++b) {
@@ -860,12 +961,19 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     const void *fns[8] = {
         reinterpret_cast<const void *>(&k_bounce<true, false>), reinterpret_cast<const void *>(&k_bounce<false, false>),
         reinterpret_cast<const void *>(&k_bounce<true, true>), reinterpret_cast<const void *>(&k_bounce<false, true>),
-        reinterpret_cast<const void *>(c->cull ? &k_bounce_seg<true, false, true> : &k_bounce_seg<true, false, false>),
-        reinterpret_cast<const void *>(c->cull ? &k_bounce_seg<false, false, true> : &k_bounce_seg<false, false, false>),
-        reinterpret_cast<const void *>(c->cull ? &k_bounce_seg<true, true, true> : &k_bounce_seg<true, true, false>),
-        reinterpret_cast<const void *>(c->cull ? &k_bounce_seg<false, true, true> : &k_bounce_seg<false, true, false>)};
-    if (c->lds_bytes > 64u * 1024u)
+        reinterpret_cast<const void *>(c->cull ? &k_bounce_seg<true, false, true, false> : &k_bounce_seg<true, false, false, false>),
+        reinterpret_cast<const void *>(c->cull ? &k_bounce_seg<false, false, true, false> : &k_bounce_seg<false, false, false, false>),
+        reinterpret_cast<const void *>(c->cull ? &k_bounce_seg<true, true, true, false> : &k_bounce_seg<true, true, false, false>),
+        reinterpret_cast<const void *>(c->cull ? &k_bounce_seg<false, true, true, false> : &k_bounce_seg<false, true, false, false>)};
+    const void *gen_fns[4] = {
+        reinterpret_cast<const void *>(c->cull ? &k_bounce_seg<true, false, true, true> : &k_bounce_seg<true, false, false, true>),
+        reinterpret_cast<const void *>(c->cull ? &k_bounce_seg<false, false, true, true> : &k_bounce_seg<false, false, false, true>),
+        reinterpret_cast<const void *>(c->cull ? &k_bounce_seg<true, true, true, true> : &k_bounce_seg<true, true, false, true>),
+        reinterpret_cast<const void *>(c->cull ? &k_bounce_seg<false, true, true, true> : &k_bounce_seg<false, true, false, true>)};
+    if (c->lds_bytes > 64u * 1024u) {
         for (const void *fn : fns) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        for (const void *fn : gen_fns) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
 
     // persistent grid: CUs x resident blocks per CU
     int per_cu = c->cfg.blocks_per_cu;
@@ -880,23 +988,32 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     if (c->seg_mode) {
         // segment size: by default one segment per resident wave (every wave gets equal work in the
         // first, largest bounce and no second round is needed); cfg.chunk_rays overrides.
-        uint32_t S;
-        if (c->cfg.chunk_rays > 0) S = ((uint32_t)c->cfg.chunk_rays + 63u) & ~63u;
-        else {
-            const uint32_t waves = (uint32_t)grid * kWaves;
-            S = (((n_own + waves - 1) / waves) + 63u) & ~63u;
-        }
-        if (S < 64u) S = 64u;
+        // Level 0: segments of S0 slots (default 64 = one full wave group).  While halving the segment
+        // count still leaves about one segment per resident wave, a bounce MERGES neighbours (the
+        // output level has 2S slots per segment): early bounces see many equal segments per wave
+        // (balanced), late bounces see few, re-densified ones (full wave groups).
+        uint32_t S = c->cfg.chunk_rays > 0 ? (uint32_t)c->cfg.chunk_rays : 192u;
+        if (S < 16u) S = 16u;
         if (S > 4096u) S = 4096u;
         c->seg_slots = S;
         c->nseg = (n_own + S - 1) / S;
-        c->cap = c->nseg * S;
+        c->cap = (c->nseg + 1u) * S;
         c->max_chunks = c->nseg;
+        const uint32_t slots = (uint32_t)grid * kWaves;
+        (void)slots;
+        const uint32_t floor_segs = (uint32_t)(c->cfg.merge_floor > 0 ? c->cfg.merge_floor : 0);
+        c->lvl_slots[0] = S; c->lvl_nseg[0] = c->nseg;
+        for (int b = 0; b < c->cfg.max_depth; ++b) {
+            const uint32_t half = (c->lvl_nseg[b] + 1u) / 2u;
+            const bool merge = c->cfg.merge_floor > 0 && half >= floor_segs && c->lvl_slots[b] * 2u <= 65536u;
+            c->lvl_slots[b + 1] = merge ? c->lvl_slots[b] * 2u : c->lvl_slots[b];
+            c->lvl_nseg[b + 1] = merge ? half : c->lvl_nseg[b];
+        }
         const uint32_t blocks_needed = (c->nseg + kWaves - 1) / kWaves;
         if ((uint32_t)grid > blocks_needed) grid = (int)blocks_needed;
         for (int i = 0; i < 2; ++i) {
-            HIPCHK(hipMalloc(&c->d_segcnt[i], (size_t)c->nseg * sizeof(uint32_t)));
-            HIPCHK(hipMemset(c->d_segcnt[i], 0, (size_t)c->nseg * sizeof(uint32_t)));
+            HIPCHK(hipMalloc(&c->d_segcnt[i], (size_t)(c->nseg + 2u) * sizeof(uint32_t)));
+            HIPCHK(hipMemset(c->d_segcnt[i], 0, (size_t)(c->nseg + 2u) * sizeof(uint32_t)));
         }
         c->status_words = 0;
     } else {
@@ -1018,7 +1135,7 @@ int pt_get_stats(pt_context *c, pt_stats *out) {
     out->generate_ms = c->ms[0]; out->bounce_ms = c->ms[1]; out->display_ms = c->ms[2];
     out->generate_launches = c->launches[0]; out->bounce_launches = c->launches[1]; out->display_launches = c->launches[2];
     out->iterations = c->iterations;
-    for (int k = 0; k <= c->cfg.max_depth && k < 65; ++k) out->live[k] = h.totals[k] + (c->counts_pending ? h.counts[k] : 0);
+    for (int k = 0; k <= c->cfg.max_depth && k < 65; ++k) out->live[k] = h.totals[k] + (c->counts_pending ? (uint64_t)h.counts[k] + h.counts_b[k] : 0);
     out->emitted = h.emitted;
     return PT_OK;
 }
@@ -1076,7 +1193,13 @@ int pt_debug_trace_pool(pt_context *c, int iteration, int bounces, int *count, f
     if (!c || !c->scene_ready || c->cfg.mode != 0) { pth::set_error("pt_debug_trace_pool: needs a path-trace context with a scene"); return PT_ERR_STATE; }
     if (bounces < 0 || bounces > c->cfg.max_depth || iteration < 1) { pth::set_error("pt_debug_trace_pool: bad bounces/iteration"); return PT_ERR_ARGUMENT; }
     HIPCHK(hipSetDevice(c->cfg.device));
-    // render into a scratch accumulator so that the hook leaves the image untouched
+    // render into a scratch accumulator and restore the counters afterwards: the hook leaves image
+    // and statistics untouched
+    HIPCHK(hipStreamSynchronize(c->stream));
+    SyncBlock snapshot;
+    HIPCHK(hipMemcpy(&snapshot, c->d_sync, sizeof snapshot, hipMemcpyDeviceToHost));
+    const bool pending = c->counts_pending;
+    const uint32_t bank_saved = c->bank;
     float *saved = c->image, *scratch = nullptr;
     HIPCHK(hipMalloc(&scratch, (size_t)c->W * c->H * 3 * sizeof(float)));
     HIPCHK(hipMemset(scratch, 0, (size_t)c->W * c->H * 3 * sizeof(float)));
@@ -1086,11 +1209,14 @@ int pt_debug_trace_pool(pt_context *c, int iteration, int bounces, int *count, f
     if (rc) { (void)hipFree(scratch); return rc; }
     HIPCHK(hipStreamSynchronize(c->stream));
     (void)hipFree(scratch);
-    uint32_t n = 0;
-    HIPCHK(hipMemcpy(&n, &c->d_sync->counts[bounces], 4, hipMemcpyDeviceToHost));
-    // this hook's counts must not pollute the stats
-    HIPCHK(hipMemset(c->d_sync->counts, 0, sizeof(uint32_t) * 72));
-    c->counts_pending = false;
+    SyncBlock after;
+    HIPCHK(hipMemcpy(&after, c->d_sync, sizeof after, hipMemcpyDeviceToHost));
+    const bool fused = c->seg_mode && bounces != 0;
+    const uint32_t n = (fused && c->bank) ? after.counts_b[bounces] : after.counts[bounces];
+    c->bank = bank_saved;
+    HIPCHK(hipMemcpy(c->d_sync, &snapshot, sizeof snapshot, hipMemcpyHostToDevice));
+    c->counts_pending = pending;
+    if (after.error) { pth::set_error("compaction look-back exceeded its spin limit"); return PT_ERR_HIP; }
     if (count) *count = (int)n;
     const float *src = c->pool[bounces & 1];
     float *dst[9] = {ox, oy, oz, dx, dy, dz, tr, tg, tb};
@@ -1100,19 +1226,20 @@ int pt_debug_trace_pool(pt_context *c, int iteration, int bounces, int *count, f
         if (pixel && n) HIPCHK(hipMemcpy(pixel, src + (size_t)9 * c->cap, (size_t)n * 4, hipMemcpyDeviceToHost));
     } else if (n) {
         // segments are dense prefixes in generation order: concatenate them
-        std::vector<uint32_t> cnt(c->nseg);
-        HIPCHK(hipMemcpy(cnt.data(), c->d_segcnt[bounces & 1], (size_t)c->nseg * 4, hipMemcpyDeviceToHost));
+        const uint32_t nseg = c->lvl_nseg[bounces], slots = c->lvl_slots[bounces];
+        std::vector<uint32_t> cnt(nseg);
+        HIPCHK(hipMemcpy(cnt.data(), c->d_segcnt[bounces & 1], (size_t)nseg * 4, hipMemcpyDeviceToHost));
         std::vector<float> field(c->cap);
         uint64_t total = 0;
-        for (uint32_t sgi = 0; sgi < c->nseg; ++sgi) total += cnt[sgi];
+        for (uint32_t sgi = 0; sgi < nseg; ++sgi) total += cnt[sgi];
         if (total != n) { pth::set_error("segment counts (%llu) disagree with the live counter (%u)", (unsigned long long)total, n); return PT_ERR_HIP; }
         for (int f = 0; f < 10; ++f) {
             float *out = f < 9 ? dst[f] : reinterpret_cast<float *>(pixel);
             if (!out) continue;
             HIPCHK(hipMemcpy(field.data(), src + (size_t)f * c->cap, (size_t)c->cap * 4, hipMemcpyDeviceToHost));
             size_t w = 0;
-            for (uint32_t sgi = 0; sgi < c->nseg; ++sgi) {
-                memcpy(out + w, field.data() + (size_t)sgi * c->seg_slots, (size_t)cnt[sgi] * 4);
+            for (uint32_t sgi = 0; sgi < nseg; ++sgi) {
+                memcpy(out + w, field.data() + (size_t)sgi * slots, (size_t)cnt[sgi] * 4);
                 w += cnt[sgi];
             }
         }

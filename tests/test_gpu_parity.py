@@ -174,7 +174,7 @@ def test_accumulation_continues_from_host_image(pt, cornell200):
     assert np.array_equal(a, want)
 
 
-@pytest.mark.parametrize("kw", [dict(geometry_path=1), dict(chunk_rays=64), dict(chunk_rays=256), dict(chunk_rays=1000), dict(blocks_per_cu=1),
+@pytest.mark.parametrize("kw", [dict(geometry_path=1), dict(chunk_rays=64), dict(chunk_rays=64, merge_floor=3000), dict(chunk_rays=1000), dict(chunk_rays=16, merge_floor=1), dict(chunk_rays=100, merge_floor=7), dict(blocks_per_cu=1),
                                 dict(culling=1), dict(culling=1, geometry_path=1), dict(compaction=1), dict(compaction=1, chunk_rays=256), dict(compaction=1, chunk_rays=1024, geometry_path=1)])
 def test_launch_variants_are_bit_identical(pt, cornell200, kw):
     ref = make_tracer(cornell200)
@@ -278,3 +278,19 @@ def test_many_primitives_scene_matches_oracle(pt, kw):
     n, arrs, pix = tr.trace_pool(2, 3)
     on, oarrs, opix = orc.trace_pool(sc, oracle_config(8), 2, 3)
     assert n == on and np.array_equal(pix, opix) and all(np.array_equal(a, b) for a, b in zip(arrs, oarrs))
+
+
+def test_stats_survive_the_parity_hook_and_repeated_iterations(pt, cornell200):
+    """live[] must count each rendered iteration once, whatever is interleaved: the pool hook, the
+    same iteration index rendered twice, odd/even iteration numbers."""
+    tr = make_tracer(cornell200)
+    tr.set_image(None)
+    _, live1 = orc.render(cornell200, oracle_config(8), 1, 1)
+    _, live3 = orc.render(cornell200, oracle_config(8), 3, 1)
+    tr.render(1, 1)
+    tr.trace_pool(5, 3)
+    tr.render(3, 1)
+    tr.trace_pool(2, 0)
+    tr.render(3, 1)
+    st = tr.stats()
+    assert [st.live[k] for k in range(9)] == [int(a) + 2 * int(b) for a, b in zip(live1, live3)]
