@@ -46,13 +46,16 @@ def reduce_to_root(tensor, dst=0):
     return tensor
 
 
-def algorithmic_bytes(stats, depth):
+def algorithmic_bytes(stats, depth, fused_generate=True):
     """HBM bytes the trace+scatter+compact launches have to move: every ray
-    entering bounce k is read once (40 B), every survivor of bounces 0..D-2 is written once
-    compacted (40 B; the last bounce writes nothing back), every path that ends on an emitter
-    reads+writes its accumulator pixel (24 B).  Geometry/material tables are LDS/L2 traffic = 0."""
+    entering bounce k >= 1 is read once (40 B) and was written once, compacted, by bounce k-1 (40 B);
+    bounce 0 generates its camera rays in registers (fused generation: nothing read) and the last
+    bounce writes nothing back; every path that ends on an emitter reads+writes its accumulator
+    pixel (24 B).  Geometry/material tables are LDS/L2 traffic = 0.  (With the look-back variant
+    k_generate writes the pool and bounce 0 reads it: that read is counted, the write belongs to
+    k_generate.)"""
     live = [int(stats.live[k]) for k in range(depth + 1)]
-    read = sum(live[k] for k in range(depth)) * RAY_BYTES
+    read = sum(live[k] for k in range(0 if not fused_generate else 1, depth)) * RAY_BYTES
     written = sum(live[k] for k in range(1, depth)) * RAY_BYTES
     return read + written + int(stats.emitted) * ACCUM_BYTES, live
 
@@ -195,7 +198,7 @@ def main():
         elapsed_events = timed_pass(args.warmup + 1, True)
 
     stats = tracer.stats()
-    nbytes, live = algorithmic_bytes(stats, depth)
+    nbytes, live = algorithmic_bytes(stats, depth, fused_generate=(args.compaction == 0))
     result = None
     if rank == 0:
         value = W * H * args.steps * depth / elapsed / 1e6
