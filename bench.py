@@ -209,7 +209,7 @@ def main():
             achieved = nbytes / (stats.bounce_ms * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-            if os.path.exists(tpath):
+            if world == 1 and os.path.exists(tpath):
                 try:
                     traffic = json.load(open(tpath)).get(args.workload, {}).get("hbm_bytes_per_launch")
                 except Exception:

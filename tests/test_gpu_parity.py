@@ -294,3 +294,51 @@ def test_stats_survive_the_parity_hook_and_repeated_iterations(pt, cornell200):
     tr.render(3, 1)
     st = tr.stats()
     assert [st.live[k] for k in range(9)] == [int(a) + 2 * int(b) for a, b in zip(live1, live3)]
+
+
+def test_config2_full_size_against_oracle(pt):
+    """BASELINE configs[1]: the sampleScene-equivalent Cornell box at its own 800x800, 8 bounces,
+    diffuse only (a few iterations of the 1000; the comparison is per iteration-exact anyway)."""
+    sc = orc.load_golden_scene("cornell")
+    assert (sc.W, sc.H) == (800, 800)
+    tr = make_tracer(sc)
+    tr.set_image(None); tr.render(1, 4)
+    want, live = orc.render(sc, oracle_config(8), 1, 4)
+    st = tr.stats()
+    assert [st.live[k] for k in range(9)] == [int(v) for v in live]
+    got = tr.image()
+    assert np.array_equal(got, want)
+    for ch in range(3):
+        assert rel_l2(got[..., ch] / 4, want[..., ch] / 4) < 1e-4
+
+
+def test_config4_and_config5_full_size_slices(pt):
+    """configs[3] (1080p, 256 primitives) and configs[4] (3840x2160, 16 bounces, Fresnel glass + thin
+    lens + jittered AA): full-size renders checked on a thin interleave of rows against the oracle,
+    plus size-independent properties (sorted compacted stream, monotone live counts)."""
+    c4 = orc.load_golden_scene("random256")
+    assert (c4.W, c4.H, c4.G) == (1920, 1080, 256)
+    tr = make_tracer(c4)
+    tr.set_image(None); tr.render(1, 1)
+    full = tr.image()
+    st = tr.stats()
+    assert all(st.live[k] >= st.live[k + 1] for k in range(8)) and st.live[0] == 1920 * 1080
+    sh_cfg = dict(row_offset=11, row_stride=270)
+    want, _ = orc.render(c4, oracle_config(8, **sh_cfg), 1, 1)
+    rows = np.arange(1080) % 270 == 11
+    assert np.array_equal(full[rows], want[rows])
+    n, arrs, pix = tr.trace_pool(1, 3)
+    assert np.all(np.diff(pix.astype(np.int64)) > 0)
+
+    c5 = orc.load_golden_scene("cornell_glass_4k")
+    assert (c5.W, c5.H) == (3840, 2160)
+    kw = dict(camera_mode=1, antialias=1, aperture=0.25, focal_distance=12.0)
+    tr5 = make_tracer(c5, depth=16, **kw)
+    tr5.set_image(None); tr5.render(1, 1)
+    full5 = tr5.image()
+    st5 = tr5.stats()
+    assert st5.live[0] == 3840 * 2160 and all(st5.live[k] >= st5.live[k + 1] for k in range(16))
+    want5, _ = orc.render(c5, oracle_config(16, row_offset=5, row_stride=540, **kw), 1, 1)
+    rows5 = np.arange(2160) % 540 == 5
+    assert np.array_equal(full5[rows5], want5[rows5])
+    assert np.isfinite(full5).all()
