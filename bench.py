@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--chunk-rays", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--merge-floor", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=0, help="iterations per launch group (0 = auto, 1 = off)")
+    ap.add_argument("--resolution", default="", help="WxH override of the scene RES line (experiments only)")
     ap.add_argument("--culling", type=int, default=0, help="0 = AABB candidate culling (default), 1 = brute force")
     ap.add_argument("--compaction", type=int, default=0, help="0 = segmented (default), 1 = look-back scan")
     args = ap.parse_args()
@@ -142,13 +144,23 @@ def main():
 
     pkg = importlib.import_module("project2-pathtracer_amd")
     scene_path, depth, desc = WORKLOADS[args.workload]
-    sf = pkg.SceneFile(os.path.join(ROOT, scene_path))
+    scene_file = os.path.join(ROOT, scene_path)
+    if args.resolution:
+        import re
+        import tempfile
+        w_, h_ = args.resolution.lower().split("x")
+        text = re.sub(r"RES\s+\d+\s+\d+", "RES         %d %d" % (int(w_), int(h_)), open(scene_file).read())
+        tmp = tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False)
+        tmp.write(text); tmp.close()
+        scene_file = tmp.name
+        desc += " [RES overridden to %s]" % args.resolution
+    sf = pkg.SceneFile(scene_file)
     geoms, mats, cam = sf.flatten(0)
     W, H = int(cam.resolution[0]), int(cam.resolution[1])
 
     tracer = pkg.PathTracer(pkg.default_config(device=device, max_depth=depth, row_offset=rank, row_stride=world,
                                                geometry_path=args.geometry_path, chunk_rays=args.chunk_rays,
-                                               blocks_per_cu=args.blocks_per_cu, culling=args.culling, merge_floor=args.merge_floor,
+                                               blocks_per_cu=args.blocks_per_cu, culling=args.culling, merge_floor=args.merge_floor, batch=args.batch,
                                                compaction=args.compaction))
     tracer.upload(geoms, mats, cam)
     accum = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda:%d" % device)

@@ -98,7 +98,11 @@ typedef struct {
                                 results identical), 1 = brute force over all primitives */
     int   merge_floor;       /* segmented mode, optional: a bounce merges neighbouring segments while the
                                 halved segment count stays >= this (0 = never merge, the default) */
-    int   reserved[4];
+    int   batch;             /* iterations that may share one launch group in pt_render (0 = auto: about
+                                32 M rays per launch, at most 32; 1 = one iteration per launch).  Results
+                                are identical: each in-flight iteration accumulates into its own plane
+                                and the planes are folded into the image in iteration order. */
+    int   reserved[3];
 } pt_config;
 
 typedef struct pt_context pt_context;

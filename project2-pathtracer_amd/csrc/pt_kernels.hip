@@ -437,7 +437,11 @@ struct SegArgs {
     int bounce;
     uint32_t iteration;
     uint32_t n_own;                  // GEN: rays of bounce 0 come from the camera, not from the pool
-    uint32_t bank;                   // counter bank of this iteration (the host alternates 0/1)
+    uint32_t n_rays;                 // = batch * n_own: `batch` consecutive iterations share one launch
+    uint32_t batch;                  // ray id = slot * n_own + local; the pool's pixel word is slot<<24 | pixel
+    float *planes;                   // batch > 1: one accumulator plane per in-flight iteration slot
+    size_t plane_stride;             //   (floats); folded into the image in iteration order afterwards
+    uint32_t bank;                   // counter bank of this launch group (the host alternates 0/1)
     CamRec cam;
 };
 
@@ -464,7 +468,7 @@ __global__ __launch_bounds__(kBlock, PT_SEG_WAVES) void k_bounce_seg(SegArgs a, 
         uint32_t *other = a.bank ? a.sync->counts : a.sync->counts_b;
         a.sync->totals[threadIdx.x] += other[threadIdx.x];
         other[threadIdx.x] = 0u;
-        if (threadIdx.x == 0) bank[0] = a.n_own;
+        if (threadIdx.x == 0) bank[0] = a.n_rays;
     }
 
     for (uint32_t seg = wslot; seg < a.nseg_out; seg += nslots) {
@@ -474,8 +478,8 @@ __global__ __launch_bounds__(kBlock, PT_SEG_WAVES) void k_bounce_seg(SegArgs a, 
         uint32_t na, nb;
         if (GEN) {                                        // level-0 segments are full except the last
             const uint32_t f0 = sa * S, f1 = f0 + S;
-            na = f0 >= a.n_own ? 0u : (a.n_own - f0 < S ? a.n_own - f0 : S);
-            nb = (!a.merge || f1 >= a.n_own) ? 0u : (a.n_own - f1 < S ? a.n_own - f1 : S);
+            na = f0 >= a.n_rays ? 0u : (a.n_rays - f0 < S ? a.n_rays - f0 : S);
+            nb = (!a.merge || f1 >= a.n_rays) ? 0u : (a.n_rays - f1 < S ? a.n_rays - f1 : S);
         } else {
             na = a.cnt_in[sa];
             nb = (a.merge && sa + 1u < a.nseg_in) ? a.cnt_in[sa + 1u] : 0u;
@@ -489,22 +493,29 @@ __global__ __launch_bounds__(kBlock, PT_SEG_WAVES) void k_bounce_seg(SegArgs a, 
             f3 o, d, thr;
             uint32_t pixel = 0u;
             if (k < n) {
+                uint32_t slot;
                 if (GEN) {
-                    // k_generate fused: local ray id -> owned pixel (row interleave) -> camera ray
+                    // k_generate fused: ray id -> (iteration slot, owned pixel via the row interleave) -> camera ray
                     const uint32_t gid = base + (k < na ? k : k - na + S);
+                    slot = a.batch > 1u ? gid / a.n_own : 0u;
+                    const uint32_t local = gid - slot * a.n_own;
                     const uint32_t W = (uint32_t)a.cam.W;
-                    const uint32_t lr = gid / W, x = gid - lr * W;
+                    const uint32_t lr = local / W, x = local - lr * W;
                     pixel = (lr * (uint32_t)a.cam.row_stride + (uint32_t)a.cam.row_offset) * W + x;
-                    camera_ray(a.cam, pixel, a.iteration, o, d);
+                    camera_ray(a.cam, pixel, a.iteration + slot, o, d);
                     thr = mk(1.0f, 1.0f, 1.0f);
                 } else {
                     const float *p = a.in + base + (k < na ? k : k - na + S);
                     o = mk(p[0 * cap], p[1 * cap], p[2 * cap]);
                     d = mk(p[3 * cap], p[4 * cap], p[5 * cap]);
                     thr = mk(p[6 * cap], p[7 * cap], p[8 * cap]);
-                    pixel = reinterpret_cast<const uint32_t *>(p)[9 * cap];
+                    const uint32_t pv = reinterpret_cast<const uint32_t *>(p)[9 * cap];
+                    slot = pv >> 24;
+                    pixel = pv & 0xFFFFFFu;
                 }
-                alive = bounce_ray<GEOM_LDS, LAST, CULL>(lg, geoms, lm, a.G, a.bounce, a.iteration, a.image, pixel, o, d, thr, emitted);
+                float *acc = a.batch > 1u ? a.planes + (size_t)slot * a.plane_stride : a.image;
+                alive = bounce_ray<GEOM_LDS, LAST, CULL>(lg, geoms, lm, a.G, a.bounce, a.iteration + slot, acc, pixel, o, d, thr, emitted);
+                pixel |= slot << 24;
             }
             const u64 ballot = __ballot(alive);
             if (!LAST && alive) {
@@ -533,6 +544,33 @@ __global__ __launch_bounds__(kBlock, PT_SEG_WAVES) void k_bounce_seg(SegArgs a, 
         if (ctrl[0]) atomicAdd(&bank[a.bounce + 1], ctrl[0]);
         if (ctrl[1]) atomicAdd(&a.sync->emitted, (u64)ctrl[1]);
     }
+}
+
+// ------------------------------------------------------------------ fold (batched iterations) ---
+// image[p] = (((image[p] + plane_0[p]) + plane_1[p]) + ...) in iteration order -- the same sum, in the
+// same order, as rendering the iterations one after the other -- and clears the planes for the next
+// batch.  One thread per owned pixel.
+struct FoldArgs {
+    float *image;
+    float *planes;
+    size_t plane_stride;
+    uint32_t batch, n_own;
+    int W, row_offset, row_stride;
+};
+
+__global__ __launch_bounds__(kBlock) void k_fold(FoldArgs a) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= a.n_own) return;
+    const uint32_t W = (uint32_t)a.W;
+    const uint32_t lr = gid / W, x = gid - lr * W;
+    const size_t p = ((size_t)(lr * (uint32_t)a.row_stride + (uint32_t)a.row_offset) * W + x) * 3;
+    float r = a.image[p], g = a.image[p + 1], b = a.image[p + 2];
+    for (uint32_t s = 0; s < a.batch; ++s) {
+        float *q = a.planes + (size_t)s * a.plane_stride + p;
+        r = r + q[0]; g = g + q[1]; b = b + q[2];
+        q[0] = 0.0f; q[1] = 0.0f; q[2] = 0.0f;
+    }
+    a.image[p] = r; a.image[p + 1] = g; a.image[p + 2] = b;
 }
 
 // ------------------------------------------------------------------ flat (reference) ---
@@ -654,6 +692,8 @@ struct pt_context {
     bool scene_ready = false;
     bool counts_pending = false;
     uint32_t bank = 0;               // counter bank of the iteration being enqueued (fused segmented path)
+    uint32_t batch_max = 1;          // iterations that may share one launch group
+    float *d_planes = nullptr;       // batch_max accumulator planes (W*H*3 floats each)
     // profiling
     struct Ev { hipEvent_t a, b; int kind; };
     std::vector<Ev> pending;
@@ -712,6 +752,8 @@ void free_scene_buffers(pt_context *c) {
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->d_display) (void)hipFree(c->d_display);
     for (int i = 0; i < 2; ++i) { if (c->d_segcnt[i]) (void)hipFree(c->d_segcnt[i]); c->d_segcnt[i] = nullptr; }
+    if (c->d_planes) (void)hipFree(c->d_planes);
+    c->d_planes = nullptr;
     if (c->image == c->image_own) c->image = nullptr;
     c->image_own = nullptr; c->d_geoms = nullptr; c->d_mats = nullptr; c->d_status = nullptr; c->d_display = nullptr;
     c->scene_ready = false;
@@ -805,21 +847,37 @@ int launch_seg(pt_context *c, const SegArgs &a, bool last, bool gen) {
     return c->geom_lds ? launch_seg_lc<true, false>(c, a, last, gen) : launch_seg_lc<false, false>(c, a, last, gen);
 }
 
-// one iteration; stop_after < 0 renders all bounces, otherwise only the first `stop_after`
-// bounces without the LAST variant (parity hook)
-int enqueue_iteration(pt_context *c, uint32_t iteration, int stop_after) {
+// segment levels for a launch group of n_rays rays: level b = layout of the pool entering bounce b
+void plan_levels(const pt_context *c, uint32_t n_rays, uint32_t *slots, uint32_t *nseg) {
+    const uint32_t S = c->seg_slots;
+    slots[0] = S; nseg[0] = (n_rays + S - 1) / S;
+    const uint32_t floor_segs = (uint32_t)(c->cfg.merge_floor > 0 ? c->cfg.merge_floor : 0);
+    for (int b = 0; b < c->cfg.max_depth; ++b) {
+        const uint32_t half = (nseg[b] + 1u) / 2u;
+        const bool merge = c->cfg.merge_floor > 0 && half >= floor_segs && slots[b] * 2u <= 65536u;
+        slots[b + 1] = merge ? slots[b] * 2u : slots[b];
+        nseg[b + 1] = merge ? half : nseg[b];
+    }
+}
+
+// `batch` consecutive iterations starting at `iteration` as ONE launch group (batch > 1: segmented
+// path only).  stop_after < 0 renders all bounces, otherwise only the first `stop_after` bounces
+// without the LAST variant (parity hook, batch = 1).
+int enqueue_iterations(pt_context *c, uint32_t iteration, uint32_t batch, int stop_after) {
     const int D = c->cfg.max_depth;
     // The segmented path generates camera rays inside its first bounce launch; k_generate runs only
     // for the look-back variant and for the parity hook that wants the pool before any bounce.
     const bool fused = c->seg_mode && stop_after != 0;
+    const uint32_t n_rays = batch * c->n_own;
+    if (c->seg_mode) plan_levels(c, n_rays, c->lvl_slots, c->lvl_nseg);
     if (!fused) {
         Scoped s(c, 0);
         GenArgs g;
         g.cam = c->cam; g.pool = c->pool[0]; g.cap = c->cap; g.n_own = c->n_own; g.iteration = iteration;
         g.sync = c->d_sync; g.status = c->d_status; g.status_words = c->seg_mode ? 0u : c->status_words; g.depth = D;
-        g.seg_cnt0 = c->seg_mode ? c->d_segcnt[0] : nullptr; g.nseg = c->nseg; g.seg_slots = c->seg_slots;
+        g.seg_cnt0 = c->seg_mode ? c->d_segcnt[0] : nullptr; g.nseg = c->lvl_nseg[0]; g.seg_slots = c->seg_slots;
         uint32_t work = c->n_own > g.status_words ? c->n_own : g.status_words;
-        if (c->seg_mode && c->nseg > work) work = c->nseg;
+        if (c->seg_mode && g.nseg > work) work = g.nseg;
         hipLaunchKernelGGL(k_generate, dim3((work + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, g);
         HIPCHK(hipGetLastError());
     }
@@ -833,9 +891,18 @@ int enqueue_iteration(pt_context *c, uint32_t iteration, int stop_after) {
         a.nseg_in = c->lvl_nseg[b]; a.nseg_out = c->lvl_nseg[b + 1]; a.seg_slots = c->lvl_slots[b];
         a.merge = c->lvl_slots[b + 1] != c->lvl_slots[b] ? 1u : 0u;
         a.bounce = b; a.iteration = iteration; a.n_own = c->n_own; a.cam = c->cam; a.bank = c->bank;
+        a.n_rays = n_rays; a.batch = batch; a.planes = c->d_planes; a.plane_stride = (size_t)c->W * c->H * 3;
         const bool last = (stop_after < 0) && (b == D - 1);
         int rc = launch_seg(c, a, last, b == 0);
         if (rc) return rc;
+    }
+    if (c->seg_mode && batch > 1u) {
+        Scoped s(c, 0);
+        FoldArgs f;
+        f.image = c->image; f.planes = c->d_planes; f.plane_stride = (size_t)c->W * c->H * 3;
+        f.batch = batch; f.n_own = c->n_own; f.W = c->W; f.row_offset = c->cfg.row_offset; f.row_stride = c->cfg.row_stride;
+        hipLaunchKernelGGL(k_fold, dim3((c->n_own + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, f);
+        HIPCHK(hipGetLastError());
     }
     for (int b = 0; b < nb && !c->seg_mode; ++b) {
         BounceArgs a;
@@ -996,19 +1063,26 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         if (S < 16u) S = 16u;
         if (S > 4096u) S = 4096u;
         c->seg_slots = S;
-        c->nseg = (n_own + S - 1) / S;
+        // iterations per launch group: explicit, or enough to put ~32 M rays into a launch (bigger
+        // launches amortise the tail of the static schedule; essential when the frame is sharded over
+        // GPUs).  The pool's pixel word keeps the slot in its top 8 bits.
+        uint32_t K = 1;
+        if (c->cfg.mode == 0 && (uint64_t)W * H <= (1ull << 24)) {
+            if (c->cfg.batch > 0) K = (uint32_t)c->cfg.batch;
+            else K = (uint32_t)((32u * 1024u * 1024u + n_own - 1) / n_own);
+            if (K > 32u) K = 32u;
+            if (K < 1u) K = 1u;
+        }
+        c->batch_max = K;
+        const uint32_t max_rays = K * n_own;
+        c->nseg = (max_rays + S - 1) / S;
         c->cap = (c->nseg + 1u) * S;
         c->max_chunks = c->nseg;
-        const uint32_t slots = (uint32_t)grid * kWaves;
-        (void)slots;
-        const uint32_t floor_segs = (uint32_t)(c->cfg.merge_floor > 0 ? c->cfg.merge_floor : 0);
-        c->lvl_slots[0] = S; c->lvl_nseg[0] = c->nseg;
-        for (int b = 0; b < c->cfg.max_depth; ++b) {
-            const uint32_t half = (c->lvl_nseg[b] + 1u) / 2u;
-            const bool merge = c->cfg.merge_floor > 0 && half >= floor_segs && c->lvl_slots[b] * 2u <= 65536u;
-            c->lvl_slots[b + 1] = merge ? c->lvl_slots[b] * 2u : c->lvl_slots[b];
-            c->lvl_nseg[b + 1] = merge ? half : c->lvl_nseg[b];
+        if (K > 1u) {
+            HIPCHK(hipMalloc(&c->d_planes, (size_t)K * W * H * 3 * sizeof(float)));
+            HIPCHK(hipMemset(c->d_planes, 0, (size_t)K * W * H * 3 * sizeof(float)));
         }
+        plan_levels(c, max_rays, c->lvl_slots, c->lvl_nseg);
         const uint32_t blocks_needed = (c->nseg + kWaves - 1) / kWaves;
         if ((uint32_t)grid > blocks_needed) grid = (int)blocks_needed;
         for (int i = 0; i < 2; ++i) {
@@ -1081,11 +1155,15 @@ int pt_render(pt_context *c, int first_iteration, int count) {
             f.n_own = c->n_own; f.write_image = 1;
             hipLaunchKernelGGL(k_flat, dim3((c->n_own + kBlock - 1) / kBlock), dim3(kBlock), tables_bytes(c->G, c->M, true), c->stream, f);
             HIPCHK(hipGetLastError());
+            c->iterations++;
         } else {
-            int rc = enqueue_iteration(c, (uint32_t)it, -1);
+            uint32_t b = (uint32_t)(first_iteration + count - it);
+            if (b > c->batch_max) b = c->batch_max;
+            int rc = enqueue_iterations(c, (uint32_t)it, b, -1);
             if (rc) return rc;
+            c->iterations += b;
+            it += (int)b - 1;
         }
-        c->iterations++;
     }
     return PT_OK;
 }
@@ -1204,7 +1282,7 @@ int pt_debug_trace_pool(pt_context *c, int iteration, int bounces, int *count, f
     HIPCHK(hipMalloc(&scratch, (size_t)c->W * c->H * 3 * sizeof(float)));
     HIPCHK(hipMemset(scratch, 0, (size_t)c->W * c->H * 3 * sizeof(float)));
     c->image = scratch;
-    int rc = enqueue_iteration(c, (uint32_t)iteration, bounces);
+    int rc = enqueue_iterations(c, (uint32_t)iteration, 1u, bounces);
     c->image = saved;
     if (rc) { (void)hipFree(scratch); return rc; }
     HIPCHK(hipStreamSynchronize(c->stream));
