@@ -223,7 +223,8 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
             if world == 1 and os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get(args.workload, {}).get("hbm_bytes_per_launch")
+                    per_step = json.load(open(tpath)).get(args.workload, {}).get("hbm_bytes_per_step")
+                    traffic = round(per_step * args.steps / launches) if per_step else None
                 except Exception:
                     traffic = None
             roof = {"bound": "hbm", "kernel": "k_bounce (trace + scatter + accumulate + stable compaction)",
