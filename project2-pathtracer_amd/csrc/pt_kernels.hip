@@ -848,8 +848,20 @@ int launch_seg(pt_context *c, const SegArgs &a, bool last, bool gen) {
 }
 
 // segment levels for a launch group of n_rays rays: level b = layout of the pool entering bounce b
+// Segment size for a launch group: fixed by cfg.chunk_rays, else about four segments per resident
+// wave, a multiple of 64 (full wave groups) between 192 and 1024 -- small launches need many small
+// segments to occupy every wave, big (batched) launches run best on long ones (measured).
+uint32_t seg_slots_for(const pt_context *c, uint32_t n_rays) {
+    if (c->cfg.chunk_rays > 0) return c->seg_slots;
+    const uint32_t slots = (uint32_t)c->grid_bounce * kWaves * 4u;
+    uint32_t S = (((n_rays + slots - 1) / slots) + 63u) & ~63u;
+    if (S < 192u) S = 192u;
+    if (S > 1024u) S = 1024u;
+    return S;
+}
+
 void plan_levels(const pt_context *c, uint32_t n_rays, uint32_t *slots, uint32_t *nseg) {
-    const uint32_t S = c->seg_slots;
+    const uint32_t S = seg_slots_for(c, n_rays);
     slots[0] = S; nseg[0] = (n_rays + S - 1) / S;
     const uint32_t floor_segs = (uint32_t)(c->cfg.merge_floor > 0 ? c->cfg.merge_floor : 0);
     for (int b = 0; b < c->cfg.max_depth; ++b) {
@@ -875,7 +887,7 @@ int enqueue_iterations(pt_context *c, uint32_t iteration, uint32_t batch, int st
         GenArgs g;
         g.cam = c->cam; g.pool = c->pool[0]; g.cap = c->cap; g.n_own = c->n_own; g.iteration = iteration;
         g.sync = c->d_sync; g.status = c->d_status; g.status_words = c->seg_mode ? 0u : c->status_words; g.depth = D;
-        g.seg_cnt0 = c->seg_mode ? c->d_segcnt[0] : nullptr; g.nseg = c->lvl_nseg[0]; g.seg_slots = c->seg_slots;
+        g.seg_cnt0 = c->seg_mode ? c->d_segcnt[0] : nullptr; g.nseg = c->lvl_nseg[0]; g.seg_slots = c->lvl_slots[0];
         uint32_t work = c->n_own > g.status_words ? c->n_own : g.status_words;
         if (c->seg_mode && g.nseg > work) work = g.nseg;
         hipLaunchKernelGGL(k_generate, dim3((work + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, g);
@@ -1075,16 +1087,18 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         }
         c->batch_max = K;
         const uint32_t max_rays = K * n_own;
-        c->nseg = (max_rays + S - 1) / S;
-        c->cap = (c->nseg + 1u) * S;
+        c->nseg = (max_rays + S - 1) / S;                 // S here = the smallest segment size in use
+        c->cap = max_rays + 2u * (c->cfg.merge_floor > 0 ? 65536u : 4096u);
         c->max_chunks = c->nseg;
         if (K > 1u) {
             HIPCHK(hipMalloc(&c->d_planes, (size_t)K * W * H * 3 * sizeof(float)));
             HIPCHK(hipMemset(c->d_planes, 0, (size_t)K * W * H * 3 * sizeof(float)));
         }
-        plan_levels(c, max_rays, c->lvl_slots, c->lvl_nseg);
         const uint32_t blocks_needed = (c->nseg + kWaves - 1) / kWaves;
         if ((uint32_t)grid > blocks_needed) grid = (int)blocks_needed;
+        if (grid < 1) grid = 1;
+        c->grid_bounce = grid;
+        plan_levels(c, max_rays, c->lvl_slots, c->lvl_nseg);
         for (int i = 0; i < 2; ++i) {
             HIPCHK(hipMalloc(&c->d_segcnt[i], (size_t)(c->nseg + 2u) * sizeof(uint32_t)));
             HIPCHK(hipMemset(c->d_segcnt[i], 0, (size_t)(c->nseg + 2u) * sizeof(uint32_t)));
