@@ -171,6 +171,10 @@ __device__ __forceinline__ int nearest_hit_culled(const GeomRec *lg, const GeomR
     for (int base = 0; base < G; base += 32) {
         const int n = (G - base) < 32 ? (G - base) : 32;
         uint32_t mask = 0u, boxbits = 0u, sphbits = 0u;
+        // nearest candidate (smallest conservative entry distance) per type: tested first, so that its
+        // exact hit lets the cheap re-check below drop the lane's other candidates
+        float near_t[2] = {3.0e38f, 3.0e38f};
+        int near_j[2] = {-1, -1};
         for (int j = 0; j < n; ++j) {                     // wave-uniform index: broadcast / scalar loads
             const GeomRec &g = tab[base + j];
             const int type = g.type;
@@ -179,13 +183,19 @@ __device__ __forceinline__ int nearest_hit_culled(const GeomRec *lg, const GeomR
             if (type == 1) { boxbits |= 1u << j; keep = cull_box(g.bmin, g.bmax, cr, tn); }
             else if (type == 0) { sphbits |= 1u << j; keep = cull_sphere(g.bmin, g.bmax, cr, tn); }
             else continue;                                // MESH: empty branch in the reference
-            if (keep) mask |= 1u << j;
+            if (keep) {
+                mask |= 1u << j;
+                const int ty = type == 1 ? 0 : 1;
+                if (tn < near_t[ty]) { near_t[ty] = tn; near_j[ty] = j; }
+            }
         }
         for (int pass = 0; pass < 2; ++pass) {
             uint32_t m = mask & (pass == 0 ? boxbits : sphbits);
+            bool first = true;
             while (m) {                                   // per-lane loop; the wave runs until all lanes are done
-                const int j = __builtin_ctz(m);
-                m &= m - 1u;
+                const int j = first ? near_j[pass] : __builtin_ctz(m);
+                first = false;
+                m &= ~(1u << j);
                 const GeomRec *g = tab + base + j;        // per-lane gather
                 if (hit >= 0) {                           // entered farther than the best exact hit: cannot win or tie
                     float tn;
