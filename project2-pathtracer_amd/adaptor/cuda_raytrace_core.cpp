@@ -22,7 +22,7 @@
 //   * errors print "Cuda error: <what>: <why>." and exit(EXIT_FAILURE) (raytraceKernel.cu:20-26).
 // Options the reference has no channel for come from the environment:
 //   PT_MODE=pathtrace|reference  PT_MAX_DEPTH  PT_CAMERA_MODE  PT_AA  PT_APERTURE  PT_FOCAL_DIST
-//   PT_DEVICE  PT_PBO_IS_DEVICE  PT_SYNC_EVERY_CALL
+//   PT_DEVICE  PT_PBO_IS_DEVICE  PT_SYNC_EVERY_CALL  PT_LAZY_BATCH
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -39,6 +39,22 @@ namespace {
 pt_context *g_ctx = nullptr;
 unsigned long long g_scene_hash = 0;
 int g_mode = 0;
+// Lazy batching behind the per-iteration API (PT_LAZY_BATCH=K, headless runs): calls only queue their
+// iteration index; the queued run is rendered as ONE pt_render(first, count) -- which the library
+// executes as a single launch group -- when K calls have accumulated, when the caller can observe the
+// result (pos != NULL, final iteration, PT_SYNC_EVERY_CALL) or when the scene changes.  What main.cpp
+// can see (camera::image after the last iteration, src/main.cpp:136-147) is unchanged.
+int g_pending_first = 0, g_pending_count = 0;
+
+void flush_pending() {
+    if (g_pending_count > 0) {
+        if (pt_render(g_ctx, g_pending_first, g_pending_count) != PT_OK) {
+            fprintf(stderr, "Cuda error: %s: %s.\n", "pt_render", pt_last_error());
+            exit(EXIT_FAILURE);
+        }
+        g_pending_count = 0;
+    }
+}
 
 [[noreturn]] void die(const char *what) {
     fprintf(stderr, "Cuda error: %s: %s.\n", what, pt_last_error());
@@ -71,6 +87,7 @@ void rows3(const cudaMat4 &m, float out[12]) {
 
 // the shim's cudaDeviceReset() (main.cpp:159,171) should call this: drops all device state
 extern "C" void ptmi355_adaptor_reset(void) {
+    g_pending_count = 0;
     if (g_ctx) pt_destroy(g_ctx);
     g_ctx = nullptr;
     g_scene_hash = 0;
@@ -116,6 +133,7 @@ void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iteratio
     h = fnv1a(materials, (size_t)numberOfMaterials * sizeof(material), h);
     h = fnv1a(&cam, sizeof cam, h);
     if (h != g_scene_hash) {
+        flush_pending();
         if (pt_upload_scene(g_ctx, pg.data(), numberOfGeoms, reinterpret_cast<const pt_material *>(materials),
                             numberOfMaterials, &cam) != PT_OK) die("pt_upload_scene");
         g_scene_hash = h;
@@ -124,13 +142,18 @@ void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iteratio
         if (pt_set_image(g_ctx, reinterpret_cast<const float *>(renderCam->image)) != PT_OK) die("pt_set_image");
     }
 
-    if (pt_render(g_ctx, iterations, 1) != PT_OK) die("pt_render");
+    const bool final_call = (unsigned)iterations >= renderCam->iterations;
+    const bool observable = PBOpos != NULL || final_call || g_mode == 1 || env_int("PT_SYNC_EVERY_CALL", 0);
+    const int lazy = env_int("PT_LAZY_BATCH", 1);
+    if (g_pending_count > 0 && g_pending_first + g_pending_count != iterations) flush_pending();   // not consecutive
+    if (g_pending_count == 0) g_pending_first = iterations;
+    g_pending_count++;
+    if (observable || g_pending_count >= lazy) flush_pending();
 
     if (PBOpos) {
         const float scale = g_mode == 1 ? 1.0f : 1.0f / (float)iterations;
         if (pt_display(g_ctx, scale, PBOpos, env_int("PT_PBO_IS_DEVICE", 0)) != PT_OK) die("pt_display");
     }
-    const bool final_call = (unsigned)iterations >= renderCam->iterations;
     if (final_call || g_mode == 1 || env_int("PT_SYNC_EVERY_CALL", 0)) {
         if (pt_get_image(g_ctx, reinterpret_cast<float *>(renderCam->image)) != PT_OK) die("Kernel failed!");
     }

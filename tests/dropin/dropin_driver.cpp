@@ -8,7 +8,8 @@
 // camera::image into the reference's `image` class, apply gamma 1/2.2 with divisor = iterations
 // (:136-147), name the file X.<frame>.bmp (:148-154) and save.  TEST INFRASTRUCTURE.
 //
-// usage: dropin_driver scene=<file> [frame=<n>] [out=<dir>]
+// usage: dropin_driver scene=<file> [frame=<n>] [out=<dir>] [pbo=0]   (pbo=0: pass pos = NULL like a run
+//        without a mapped display buffer)
 #include <cstdio>
 #include <cstring>
 #include <iostream>
@@ -27,6 +28,7 @@ int main(int argc, char **argv) {
     scene *renderScene = NULL;
     int targetFrame = 0;
     std::string outdir;
+    bool use_pbo = true;
     for (int i = 1; i < argc; i++) {
         std::string header, data;
         std::istringstream liness(argv[i]);
@@ -35,6 +37,7 @@ int main(int argc, char **argv) {
         if (header == "scene") renderScene = new scene(data);
         else if (header == "frame") targetFrame = atoi(data.c_str());
         else if (header == "out") outdir = data;
+        else if (header == "pbo") use_pbo = atoi(data.c_str()) != 0;
     }
     if (!renderScene) { std::cout << "Error: scene file needed!" << std::endl; return 0; }
     camera *renderCam = &renderScene->renderCam;
@@ -46,7 +49,7 @@ int main(int argc, char **argv) {
         material *materials = new material[renderScene->materials.size()];
         for (size_t i = 0; i < renderScene->objects.size(); i++) geoms[i] = renderScene->objects[i];
         for (size_t i = 0; i < renderScene->materials.size(); i++) materials[i] = renderScene->materials[i];
-        cudaRaytraceCore(pbo, renderCam, targetFrame, iterations, materials, (int)renderScene->materials.size(),
+        cudaRaytraceCore(use_pbo ? pbo : NULL, renderCam, targetFrame, iterations, materials, (int)renderScene->materials.size(),
                          geoms, (int)renderScene->objects.size());
         delete[] geoms;
         delete[] materials;

@@ -100,3 +100,21 @@ def test_path_trace_through_reference_host_code(tmp_path):
         px = (want.reshape(-1, 3)[idx] * scale).astype(np.float32)
         orc.lib().orc_display_pixel(orc.vec3(*px), o)
         assert list(pbo[idx]) == list(o)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref/dropin_driver not built")
+def test_lazy_batching_behind_the_per_iteration_api(tmp_path):
+    """PT_LAZY_BATCH: the adaptor queues per-iteration calls and renders them as one launch group;
+    what the caller can observe (camera::image after the last iteration) is bit-identical."""
+    scene_path = _small_scene(tmp_path, 64, 48, 7)
+    outs = []
+    for lazy, sub in (("1", "a"), ("4", "b"), ("16", "c")):
+        out = tmp_path / sub
+        out.mkdir()
+        env = dict(os.environ, PT_MODE="pathtrace", PT_MAX_DEPTH="5", PT_LAZY_BATCH=lazy)
+        r = subprocess.run([DRIVER, "scene=" + scene_path, "out=" + str(out), "pbo=0"], capture_output=True, text=True, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr
+        outs.append(np.fromfile(str(out / "cornell_mirror.0.bmp.f32"), np.float32))
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert outs[0].max() > 0
