@@ -161,6 +161,10 @@ __device__ __forceinline__ bool cull_sphere(const float *bmin, const float *bmax
     return !((perp2 > lim) || (b < 0.0f && c2 > lim));
 }
 
+#ifdef PT_CULL_STATS
+__device__ unsigned long long g_cull_stats[8];   // [0] groups, [1] box iters, [2] box active lanes, [3] sph iters, [4] sph active lanes, [5] candidates
+#endif
+
 template <bool GEOM_LDS>
 __device__ __forceinline__ int nearest_hit_culled(const GeomRec *lg, const GeomRec *__restrict__ gg, int G, f3 o, f3 d,
                                                   float &tbest, f3 &P, f3 &N) {
@@ -189,10 +193,23 @@ __device__ __forceinline__ int nearest_hit_culled(const GeomRec *lg, const GeomR
                 if (tn < near_t[ty]) { near_t[ty] = tn; near_j[ty] = j; }
             }
         }
+#ifdef PT_CULL_STATS
+        if ((threadIdx.x & 63) == 0) atomicAdd(&g_cull_stats[0], 1ull);
+        atomicAdd(&g_cull_stats[5], (unsigned long long)__popc(mask));
+#endif
         for (int pass = 0; pass < 2; ++pass) {
             uint32_t m = mask & (pass == 0 ? boxbits : sphbits);
             bool first = true;
             while (m) {                                   // per-lane loop; the wave runs until all lanes are done
+#ifdef PT_CULL_STATS
+                {
+                    const unsigned long long act = __ballot(1);
+                    if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(act)) {
+                        atomicAdd(&g_cull_stats[1 + 2 * pass], 1ull);
+                        atomicAdd(&g_cull_stats[2 + 2 * pass], (unsigned long long)__popcll(act));
+                    }
+                }
+#endif
                 const int j = first ? near_j[pass] : __builtin_ctz(m);
                 first = false;
                 m &= ~(1u << j);
@@ -1218,6 +1235,12 @@ int pt_display(pt_context *c, float scale, void *out, int out_is_device) {
     }
     return PT_OK;
 }
+
+#ifdef PT_CULL_STATS
+int pt_debug_cull_stats(unsigned long long *out8) {
+    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_cull_stats), 64) == hipSuccess ? 0 : -2;
+}
+#endif
 
 int pt_set_profiling(pt_context *c, int enabled) {
     if (!c) { pth::set_error("pt_set_profiling: null context"); return PT_ERR_ARGUMENT; }
