@@ -532,11 +532,14 @@ __global__ __launch_bounds__(kBlock, PT_SEG_WAVES) void k_bounce_seg(SegArgs a, 
                     camera_ray(a.cam, pixel, a.iteration + slot, o, d);
                     thr = mk(1.0f, 1.0f, 1.0f);
                 } else {
-                    const float *p = a.in + base + (k < na ? k : k - na + S);
-                    o = mk(p[0 * cap], p[1 * cap], p[2 * cap]);
-                    d = mk(p[3 * cap], p[4 * cap], p[5 * cap]);
-                    thr = mk(p[6 * cap], p[7 * cap], p[8 * cap]);
-                    const uint32_t pv = reinterpret_cast<const uint32_t *>(p)[9 * cap];
+                    // wave-uniform field bases (SGPR) + one 32-bit lane offset: `global_load_dword v, v_off, s[base]`
+                    const uint32_t idx = base + (k < na ? k : k - na + S);
+                    __builtin_assume(idx < (1u << 29));
+                    const float *in = a.in;
+                    o = mk(in[idx], (in + cap)[idx], (in + 2 * cap)[idx]);
+                    d = mk((in + 3 * cap)[idx], (in + 4 * cap)[idx], (in + 5 * cap)[idx]);
+                    thr = mk((in + 6 * cap)[idx], (in + 7 * cap)[idx], (in + 8 * cap)[idx]);
+                    const uint32_t pv = reinterpret_cast<const uint32_t *>(in + 9 * cap)[idx];
                     slot = pv >> 24;
                     pixel = pv & 0xFFFFFFu;
                 }
@@ -548,11 +551,13 @@ __global__ __launch_bounds__(kBlock, PT_SEG_WAVES) void k_bounce_seg(SegArgs a, 
             if (!LAST && alive) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32),
                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
-                float *q = a.out + base + running + rank;
-                q[0 * cap] = o.x; q[1 * cap] = o.y; q[2 * cap] = o.z;
-                q[3 * cap] = d.x; q[4 * cap] = d.y; q[5 * cap] = d.z;
-                q[6 * cap] = thr.x; q[7 * cap] = thr.y; q[8 * cap] = thr.z;
-                reinterpret_cast<uint32_t *>(q)[9 * cap] = pixel;
+                const uint32_t oi = base + running + rank;
+                __builtin_assume(oi < (1u << 29));
+                float *out = a.out;
+                out[oi] = o.x; (out + cap)[oi] = o.y; (out + 2 * cap)[oi] = o.z;
+                (out + 3 * cap)[oi] = d.x; (out + 4 * cap)[oi] = d.y; (out + 5 * cap)[oi] = d.z;
+                (out + 6 * cap)[oi] = thr.x; (out + 7 * cap)[oi] = thr.y; (out + 8 * cap)[oi] = thr.z;
+                reinterpret_cast<uint32_t *>(out + 9 * cap)[oi] = pixel;
             }
             running += (uint32_t)__popcll(ballot);
         }
