@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--chunk-rays", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--merge-floor", type=int, default=0)
+    ap.add_argument("--ordering", type=int, default=1, help="1 = sparse-work queue (fastest; default here), 0 = stable compaction (the library default)")
     ap.add_argument("--batch", type=int, default=0, help="iterations per launch group (0 = auto, 1 = off)")
     ap.add_argument("--resolution", default="", help="WxH override of the scene RES line (experiments only)")
     ap.add_argument("--culling", type=int, default=0, help="0 = AABB candidate culling (default), 1 = brute force")
@@ -160,7 +161,7 @@ def main():
 
     tracer = pkg.PathTracer(pkg.default_config(device=device, max_depth=depth, row_offset=rank, row_stride=world,
                                                geometry_path=args.geometry_path, chunk_rays=args.chunk_rays,
-                                               blocks_per_cu=args.blocks_per_cu, culling=args.culling, merge_floor=args.merge_floor, batch=args.batch,
+                                               blocks_per_cu=args.blocks_per_cu, culling=args.culling, merge_floor=args.merge_floor, batch=args.batch, ordering=args.ordering,
                                                compaction=args.compaction))
     tracer.upload(geoms, mats, cam)
     accum = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda:%d" % device)
@@ -240,6 +241,7 @@ def main():
             "config": {"workload": desc, "scene": scene_path, "resolution": [W, H], "bounces": depth,
                        "rays_per_step": W * H, "sharding": "rows interleaved over %d GPU(s), 1 RCCL reduce per frame" % world,
                        "live_ray_bounces_per_step": round(sum(live[:depth]) / max(1, int(stats.iterations))),
+                       "compaction": ("segmented, wave-autonomous; " + ("sparse-work queue (ordering=1)" if args.ordering == 1 else "stable order (ordering=0)")) if args.compaction == 0 else "global look-back scan",
                        "ms_per_step_with_kernel_events": round(elapsed_events / args.steps * 1e3, 4) if elapsed_events else None},
             "roofline": roof,
         }

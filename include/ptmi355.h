@@ -102,7 +102,11 @@ typedef struct {
                                 32 M rays per launch, at most 32; 1 = one iteration per launch).  Results
                                 are identical: each in-flight iteration accumulates into its own plane
                                 and the planes are folded into the image in iteration order. */
-    int   reserved[3];
+    int   ordering;          /* 0 = stable: the compacted stream keeps generation order (default)
+                                1 = sparse-work queue: rays with non-trivial candidate sets are gathered
+                                    into dense wave groups inside their segment (faster; survivors keep
+                                    their segment but not their order inside it; results identical) */
+    int   reserved[2];
 } pt_config;
 
 typedef struct pt_context pt_context;
@@ -175,6 +179,9 @@ int  pt_debug_rng_from_thread(pt_context *ctx, float resx, float resy, float tim
 /* device evaluations of the scatter primitives for n inputs (interactions.h signatures) */
 int  pt_debug_hemisphere(pt_context *ctx, int n, const float *normal3, const float *xi2, float *out3);
 int  pt_debug_sincos(pt_context *ctx, int n, const float *a, float *s, float *c);
+/* getRandomPointOnCube / getRandomPointOnSphere (src/intersections.h:220-286) on primitive `geom`
+ * of the uploaded scene for n float seeds (the reference's light-sampling helpers; no call sites there) */
+int  pt_debug_light_points(pt_context *ctx, int geom, int n, const float *seeds, float *out3);
 
 /* ---- host-side scene I/O (no GPU needed; src/scene.cpp grammar, src/image.cpp output) ---- */
 

@@ -293,6 +293,61 @@ int orc_nearest_hit(const orc_geom *geoms, int ngeoms, const orc_material *mats,
     return hit;
 }
 
+/* ------------------------------------------------------------------ light sampling - */
+
+/* getRadiuses (src/intersections.h:207-216): half-dimensions of the transformed unit cube */
+void orc_get_radiuses(const orc_geom *g, float out[3]) {
+    v3 origin = mulmv(g->transform, V(0.0f, 0.0f, 0.0f), 1.0f);
+    v3 xmax = mulmv(g->transform, V(.5f, 0.0f, 0.0f), 1.0f);
+    v3 ymax = mulmv(g->transform, V(0.0f, .5f, 0.0f), 1.0f);
+    v3 zmax = mulmv(g->transform, V(0.0f, 0.0f, .5f), 1.0f);
+    out[0] = vlength(vsub(xmax, origin));         /* glm::distance(p0,p1) = length(p1-p0) */
+    out[1] = vlength(vsub(ymax, origin));
+    out[2] = vlength(vsub(zmax, origin));
+}
+
+/* uniform_real_distribution<float>(a,b): u01*(b-a) + a */
+static inline float dist_ab(uint32_t x, float a, float b) { return (orc_u01(x) * (b - a)) + a; }
+
+/* getRandomPointOnCube (src/intersections.h:220-262).  No call sites in the reference; restated for
+ * completeness ("parity unpinned": intersections.h cannot be built here).  `hash(randomSeed)` converts
+ * the float seed to unsigned by truncation; the two u02 draws inside one glm::vec3(...) constructor are
+ * unsequenced in C++ -- taken left to right. */
+void orc_random_point_on_cube(const orc_geom *cube, float randomSeed, float out[3]) {
+    uint32_t st = orc_lcg_seed(orc_hash((uint32_t)randomSeed));
+    float radii[3];
+    orc_get_radiuses(cube, radii);
+    float side1 = radii[0] * radii[1] * 4.0f;
+    float side2 = radii[2] * radii[1] * 4.0f;
+    float side3 = radii[0] * radii[2] * 4.0f;
+    float totalarea = 2.0f * (side1 + side2 + side3);
+    st = orc_lcg_next(st);
+    float russianRoulette = orc_u01(st);
+    st = orc_lcg_next(st); float a = dist_ab(st, -0.5f, 0.5f);
+    st = orc_lcg_next(st); float b = dist_ab(st, -0.5f, 0.5f);
+    v3 point;
+    if (russianRoulette < (side1 / totalarea)) point = V(a, b, .5f);
+    else if (russianRoulette < ((side1 * 2) / totalarea)) point = V(a, b, -.5f);
+    else if (russianRoulette < (((side1 * 2) + (side2)) / totalarea)) point = V(.5f, a, b);
+    else if (russianRoulette < (((side1 * 2) + (side2 * 2)) / totalarea)) point = V(-.5f, a, b);
+    else if (russianRoulette < (((side1 * 2) + (side2 * 2) + (side3)) / totalarea)) point = V(a, .5f, b);
+    else point = V(a, -.5f, b);
+    vstore(out, mulmv(cube->transform, point, 1.0f));
+}
+
+/* getRandomPointOnSphere (src/intersections.h:265-286): x,y ~ U(-.5,.5), z = +-sqrt(r^2-x^2-y^2) -- as
+ * shipped this is neither uniform nor always real (x^2+y^2 can exceed r^2 = .25 -> NaN); restated as is. */
+void orc_random_point_on_sphere(const orc_geom *sphere, float randomSeed, float out[3]) {
+    const float radius = .5f;
+    uint32_t st = orc_lcg_seed(orc_hash((uint32_t)randomSeed));
+    st = orc_lcg_next(st); float x = dist_ab(st, -0.5f, 0.5f);
+    st = orc_lcg_next(st); float y = dist_ab(st, -0.5f, 0.5f);
+    st = orc_lcg_next(st); float russianRoulette = orc_u01(st);
+    float z = sqrtf(radius * radius - x * x - y * y);
+    if (!(russianRoulette < 0.5f)) z = -z;
+    vstore(out, mulmv(sphere->transform, V(x, y, z), 1.0f));
+}
+
 /* ------------------------------------------------------------------ scatter ------ */
 
 /* src/interactions.h:62-87 */

@@ -19,6 +19,7 @@
  *   orc_multiply_mv               src/intersections.h:53-59
  *   orc_sphere_test               src/intersections.h:168-204 (+ getPointOnRay :46-48)
  *   orc_box_test                  src/intersections.h:73-164
+ *   orc_get_radiuses / orc_random_point_on_cube / _sphere   src/intersections.h:207-286
  *   orc_hemisphere                src/interactions.h:62-87 (calculateRandomDirectionInHemisphere)
  *   orc_build_transform           src/utilities.cpp:70-86 + GLM 0.9.3.4 translate/rotate/scale/
  *                                 inverse (src/glm/gtc/matrix_transform.inl:32-103,
@@ -130,6 +131,9 @@ float orc_box_test(const orc_geom *g, int inside_hits, const float o[3], const f
 int   orc_nearest_hit(const orc_geom *geoms, int ngeoms, const orc_material *mats,
                       const float o[3], const float d[3], float *t, float P[3], float N[3]);
 
+void  orc_get_radiuses(const orc_geom *g, float out[3]);
+void  orc_random_point_on_cube(const orc_geom *cube, float randomSeed, float out[3]);
+void  orc_random_point_on_sphere(const orc_geom *sphere, float randomSeed, float out[3]);
 void  orc_hemisphere(const float n[3], float xi1, float xi2, float out[3]);
 void  orc_reflection_direction(const float n[3], const float i[3], float out[3]);
 int   orc_transmission_direction(const float n[3], const float i[3], float ior_i, float ior_t,

@@ -46,7 +46,7 @@ class Config(C.Structure):     # == pt_config
                 ("antialias", C.c_int), ("aperture", C.c_float), ("focal_distance", C.c_float),
                 ("row_offset", C.c_int), ("row_stride", C.c_int), ("geometry_path", C.c_int),
                 ("chunk_rays", C.c_int), ("blocks_per_cu", C.c_int), ("profile", C.c_int),
-                ("compaction", C.c_int), ("culling", C.c_int), ("merge_floor", C.c_int), ("batch", C.c_int), ("reserved", C.c_int * 3)]
+                ("compaction", C.c_int), ("culling", C.c_int), ("merge_floor", C.c_int), ("batch", C.c_int), ("ordering", C.c_int), ("reserved", C.c_int * 2)]
 
 
 class Stats(C.Structure):      # == pt_stats
@@ -95,6 +95,7 @@ def lib():
     L.pt_debug_rng_from_thread.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_int, ip, fp]
     L.pt_debug_hemisphere.argtypes = [vp, C.c_int, fp, fp, fp]
     L.pt_debug_sincos.argtypes = [vp, C.c_int, fp, fp, fp]
+    L.pt_debug_light_points.argtypes = [vp, C.c_int, C.c_int, fp, fp]
     L.pt_scene_load.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.pt_scene_free.argtypes = [vp]; L.pt_scene_free.restype = None
     L.pt_scene_counts.argtypes = [vp, ip, ip, ip, ip]
@@ -112,7 +113,7 @@ EXPORTS = [
     "pt_abi_version", "pt_last_error", "pt_config_default", "pt_device_count", "pt_create", "pt_destroy",
     "pt_upload_scene", "pt_set_image", "pt_bind_device_image", "pt_get_image", "pt_render", "pt_sync",
     "pt_display", "pt_set_profiling", "pt_get_stats", "pt_reset_stats", "pt_get_resolution", "pt_debug_primary_hits",
-    "pt_debug_trace_pool", "pt_debug_rng_from_thread", "pt_debug_hemisphere", "pt_debug_sincos",
+    "pt_debug_trace_pool", "pt_debug_rng_from_thread", "pt_debug_hemisphere", "pt_debug_sincos", "pt_debug_light_points",
     "pt_scene_load", "pt_scene_free", "pt_scene_counts", "pt_scene_image_name", "pt_scene_flatten",
     "pt_scene_object_matrices", "pt_build_transform", "pt_image_to_u8", "pt_image_save",
 ]
@@ -257,6 +258,12 @@ class PathTracer:
         xi = np.ascontiguousarray(xi, np.float32)
         out = np.zeros_like(normals)
         _check(lib().pt_debug_hemisphere(self._h, len(normals), _fp(normals), _fp(xi), _fp(out)))
+        return out
+
+    def light_points(self, geom, seeds):
+        seeds = np.ascontiguousarray(seeds, np.float32)
+        out = np.zeros((len(seeds), 3), np.float32)
+        _check(lib().pt_debug_light_points(self._h, geom, len(seeds), _fp(seeds), _fp(out)))
         return out
 
     def sincos(self, a):

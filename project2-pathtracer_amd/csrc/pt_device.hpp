@@ -195,6 +195,49 @@ __device__ __forceinline__ float box_test(const float *inv, const float *xf, int
     return length(wp - o);
 }
 
+// ---------------------------------------------------------------- light sampling -------
+// getRadiuses / getRandomPointOnCube / getRandomPointOnSphere (src/intersections.h:207-286): no
+// call sites in the reference; provided (and parity-tested against the oracle) for next-event
+// estimation.  Quirks kept: float seed truncated to unsigned, sphere sampler non-uniform / NaN-prone.
+__device__ __forceinline__ f3 get_radiuses(const float *xf) {
+    const f3 origin = mul_point(xf, mk(0.0f, 0.0f, 0.0f));
+    const f3 xmax = mul_point(xf, mk(.5f, 0.0f, 0.0f));
+    const f3 ymax = mul_point(xf, mk(0.0f, .5f, 0.0f));
+    const f3 zmax = mul_point(xf, mk(0.0f, 0.0f, .5f));
+    return mk(length(xmax - origin), length(ymax - origin), length(zmax - origin));
+}
+__device__ __forceinline__ float dist_ab(uint32_t x, float a, float b) { return (u01(x) * (b - a)) + a; }
+
+__device__ __forceinline__ f3 random_point_on_cube(const float *xf, float randomSeed) {
+    uint32_t st = lcg_seed(hash((uint32_t)randomSeed));
+    const f3 radii = get_radiuses(xf);
+    const float side1 = radii.x * radii.y * 4.0f;
+    const float side2 = radii.z * radii.y * 4.0f;
+    const float side3 = radii.x * radii.z * 4.0f;
+    const float totalarea = 2.0f * (side1 + side2 + side3);
+    st = lcg_next(st); const float rr = u01(st);
+    st = lcg_next(st); const float a = dist_ab(st, -0.5f, 0.5f);
+    st = lcg_next(st); const float b = dist_ab(st, -0.5f, 0.5f);
+    f3 point;
+    if (rr < (side1 / totalarea)) point = mk(a, b, .5f);
+    else if (rr < ((side1 * 2) / totalarea)) point = mk(a, b, -.5f);
+    else if (rr < (((side1 * 2) + (side2)) / totalarea)) point = mk(.5f, a, b);
+    else if (rr < (((side1 * 2) + (side2 * 2)) / totalarea)) point = mk(-.5f, a, b);
+    else if (rr < (((side1 * 2) + (side2 * 2) + (side3)) / totalarea)) point = mk(a, .5f, b);
+    else point = mk(a, -.5f, b);
+    return mul_point(xf, point);
+}
+
+__device__ __forceinline__ f3 random_point_on_sphere(const float *xf, float randomSeed) {
+    uint32_t st = lcg_seed(hash((uint32_t)randomSeed));
+    st = lcg_next(st); const float x = dist_ab(st, -0.5f, 0.5f);
+    st = lcg_next(st); const float y = dist_ab(st, -0.5f, 0.5f);
+    st = lcg_next(st); const float rr = u01(st);
+    float z = __builtin_sqrtf(0.5f * 0.5f - x * x - y * y);
+    if (!(rr < 0.5f)) z = -z;
+    return mul_point(xf, mk(x, y, z));
+}
+
 // ---------------------------------------------------------------- scatter --------------
 // calculateRandomDirectionInHemisphere (src/interactions.h:62-87)
 __device__ __forceinline__ f3 hemisphere(f3 normal, float xi1, float xi2) {

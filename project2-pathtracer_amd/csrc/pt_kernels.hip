@@ -296,6 +296,27 @@ __global__ __launch_bounds__(kBlock) void k_generate(GenArgs a) {
 // ------------------------------------------------------------------ one ray, one bounce -
 // nearest hit -> material -> scatter / emit.  Returns true while the path stays alive; o, d, thr
 // are updated in place.  LAST: depth exhausted -- only emitters matter, survivors are counted.
+// material -> scatter / emit for a ray whose nearest hit is known.  Returns true while the path stays
+// alive; o, d, thr are updated in place.  LAST: depth exhausted -- only emitters matter.
+template <bool LAST>
+__device__ __forceinline__ bool shade_hit(const MatRec m, f3 P, f3 N, int bounce, uint32_t iteration, float *image,
+                                          uint32_t pixel, f3 &o, f3 &d, f3 &thr, uint32_t &emitted) {
+    if (LAST && !(m.emittance > 0.0f)) return true;       // depth exhausted: alive, contributes 0
+    uint32_t st = lcg_seed(stream_seed(pixel, iteration, 1u + (uint32_t)bounce));
+    st = lcg_next(st); const float u_sel = u01(st);
+    st = lcg_next(st); const float xi1 = u01(st);
+    st = lcg_next(st); const float xi2 = u01(st);
+    f3 L = mk(0.0f, 0.0f, 0.0f);
+    const int code = scatter(m, P, N, u_sel, xi1, xi2, o, d, thr, L);
+    if (code == 3) {
+        // exactly one live path per pixel per iteration (slot): plain read-modify-write, no atomics
+        float *px = image + (size_t)pixel * 3;
+        px[0] = px[0] + L.x; px[1] = px[1] + L.y; px[2] = px[2] + L.z;
+        emitted++;
+    }
+    return code <= 2;
+}
+
 template <bool GEOM_LDS, bool LAST, bool CULL>
 __device__ __forceinline__ bool bounce_ray(const GeomRec *lg, const GeomRec *__restrict__ geoms, const MatRec *lm,
                                            int G, int bounce, uint32_t iteration, float *image, uint32_t pixel,
@@ -308,21 +329,7 @@ __device__ __forceinline__ bool bounce_ray(const GeomRec *lg, const GeomRec *__r
     else hit = nearest_hit(geoms, G, o, d, t, P, N);
     if (hit < 0) return false;
     const int mid = GEOM_LDS ? lg[hit].mat : geoms[hit].mat;
-    const MatRec m = lm[mid];
-    if (LAST && !(m.emittance > 0.0f)) return true;       // depth exhausted: alive, contributes 0
-    uint32_t st = lcg_seed(stream_seed(pixel, iteration, 1u + (uint32_t)bounce));
-    st = lcg_next(st); const float u_sel = u01(st);
-    st = lcg_next(st); const float xi1 = u01(st);
-    st = lcg_next(st); const float xi2 = u01(st);
-    f3 L = mk(0.0f, 0.0f, 0.0f);
-    const int code = scatter(m, P, N, u_sel, xi1, xi2, o, d, thr, L);
-    if (code == 3) {
-        // exactly one live path per pixel per iteration: plain read-modify-write, no atomics
-        float *px = image + (size_t)pixel * 3;
-        px[0] = px[0] + L.x; px[1] = px[1] + L.y; px[2] = px[2] + L.z;
-        emitted++;
-    }
-    return code <= 2;
+    return shade_hit<LAST>(lm[mid], P, N, bounce, iteration, image, pixel, o, d, thr, emitted);
 }
 
 // ------------------------------------------------------------------ bounce -------------
@@ -578,6 +585,205 @@ __global__ __launch_bounds__(kBlock, PT_SEG_WAVES) void k_bounce_seg(SegArgs a, 
     }
 }
 
+// ------------------------------------------------------------------ bounce, sparse-work queue ---
+// Same work as k_bounce_seg with culling, organised so that the exact-test loops run on full waves.
+// Measured on the Cornell box (tools/cullstats.py): per 64-ray group the exact cube loop runs 1.43
+// times at 31 active lanes and the exact sphere loop 0.96 times at 6 active lanes -- the second and
+// the sphere rounds are paid by the whole wave for a handful of rays.  Here a lane whose candidate set
+// is not trivial (a sphere candidate, or more than one cube candidate) does not hold its wave up:
+// its ray (11 dwords incl. the candidate mask) goes to a wave-private LDS ring, the wave finishes
+// the simple lanes (at most ONE exact cube test each), and whenever 64 deferred rays have gathered
+// they are popped and run through the general per-lane loop as one dense group.  A segment's ring is
+// drained before the wave leaves the segment, so every survivor still lands in its own segment --
+// but not in generation order inside it (deterministic, results identical; `ordering` in DESIGN.md).
+constexpr uint32_t kQueueCap = 128;      // entries per wave ring (a power of two >= 2*64 - 1)
+constexpr uint32_t kQueueFields = 11;    // o d thr pixelword mask
+
+template <bool LAST, bool GEN>
+__global__ __launch_bounds__(kBlock, PT_SEG_WAVES) void k_bounce_defer(SegArgs a, const GeomRec *__restrict__ geoms,
+                                                                       const MatRec *__restrict__ mats) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t *ctrl = reinterpret_cast<uint32_t *>(smem);   // [0] survivors, [1] emitted (block sums)
+    if (threadIdx.x < 2) ctrl[threadIdx.x] = 0u;
+    GeomRec *lg;
+    MatRec *lm;
+    stage_tables(smem, geoms, a.G, mats, a.M, true, lg, lm);        // ends with __syncthreads()
+
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t wslot = blockIdx.x * kWaves + wave, nslots = gridDim.x * kWaves;
+    const size_t cap = a.cap;
+    const uint32_t S = a.seg_slots;
+    uint32_t emitted = 0u, survivors = 0u;
+    float *ring = reinterpret_cast<float *>(smem + tables_bytes(a.G, a.M, true)) + (size_t)wave * kQueueCap * kQueueFields;
+
+    uint32_t *bank = a.bank ? a.sync->counts_b : a.sync->counts;
+    if (GEN && blockIdx.x == 0 && threadIdx.x < 72) {
+        uint32_t *other = a.bank ? a.sync->counts : a.sync->counts_b;
+        a.sync->totals[threadIdx.x] += other[threadIdx.x];
+        other[threadIdx.x] = 0u;
+        if (threadIdx.x == 0) bank[0] = a.n_rays;
+    }
+
+    // primitive types as bit sets (wave-uniform; G <= 32 on this path)
+    uint32_t boxbits = 0u, sphbits = 0u;
+    for (int j = 0; j < a.G; ++j) {
+        const int type = lg[j].type;
+        if (type == 1) boxbits |= 1u << j;
+        else if (type == 0) sphbits |= 1u << j;
+    }
+
+    uint32_t qhead = 0u, qcount = 0u;                     // wave-uniform ring state
+    for (uint32_t seg = wslot; seg < a.nseg_out; seg += nslots) {
+        const uint32_t sa = a.merge ? 2u * seg : seg;
+        uint32_t na, nb;
+        if (GEN) {
+            const uint32_t f0 = sa * S, f1 = f0 + S;
+            na = f0 >= a.n_rays ? 0u : (a.n_rays - f0 < S ? a.n_rays - f0 : S);
+            nb = (!a.merge || f1 >= a.n_rays) ? 0u : (a.n_rays - f1 < S ? a.n_rays - f1 : S);
+        } else {
+            na = a.cnt_in[sa];
+            nb = (a.merge && sa + 1u < a.nseg_in) ? a.cnt_in[sa + 1u] : 0u;
+        }
+        const uint32_t n = na + nb;
+        const uint32_t base = sa * S;
+        uint32_t running = 0u, g = 0u;
+        for (;;) {
+            const bool fresh_left = g < n;
+            const bool from_q = qcount >= 64u || (!fresh_left && qcount > 0u);
+            if (!from_q && !fresh_left) break;
+            bool valid;
+            f3 o = mk(0, 0, 0), d = mk(0, 0, 0), thr = mk(0, 0, 0);
+            uint32_t pv = 0u, mask = 0u;
+            if (from_q) {
+                const uint32_t cnt = qcount < 64u ? qcount : 64u;
+                valid = lane < cnt;
+                if (valid) {
+                    const float *q = ring + ((qhead + lane) & (kQueueCap - 1u));
+                    o = mk(q[0 * kQueueCap], q[1 * kQueueCap], q[2 * kQueueCap]);
+                    d = mk(q[3 * kQueueCap], q[4 * kQueueCap], q[5 * kQueueCap]);
+                    thr = mk(q[6 * kQueueCap], q[7 * kQueueCap], q[8 * kQueueCap]);
+                    pv = __float_as_uint(q[9 * kQueueCap]);
+                    mask = __float_as_uint(q[10 * kQueueCap]);
+                }
+                qhead = (qhead + cnt) & (kQueueCap - 1u);
+                qcount -= cnt;
+            } else {
+                const uint32_t k = g + lane;
+                g += 64u;
+                valid = k < n;
+                if (valid) {
+                    if (GEN) {
+                        const uint32_t gid = base + (k < na ? k : k - na + S);
+                        const uint32_t slot = a.batch > 1u ? gid / a.n_own : 0u;
+                        const uint32_t local = gid - slot * a.n_own;
+                        const uint32_t W = (uint32_t)a.cam.W;
+                        const uint32_t lr = local / W, x = local - lr * W;
+                        const uint32_t pixel = (lr * (uint32_t)a.cam.row_stride + (uint32_t)a.cam.row_offset) * W + x;
+                        camera_ray(a.cam, pixel, a.iteration + slot, o, d);
+                        thr = mk(1.0f, 1.0f, 1.0f);
+                        pv = pixel | (slot << 24);
+                    } else {
+                        const uint32_t idx = base + (k < na ? k : k - na + S);
+                        const float *in = a.in;
+                        o = mk(in[idx], (in + cap)[idx], (in + 2 * cap)[idx]);
+                        d = mk((in + 3 * cap)[idx], (in + 4 * cap)[idx], (in + 5 * cap)[idx]);
+                        thr = mk((in + 6 * cap)[idx], (in + 7 * cap)[idx], (in + 8 * cap)[idx]);
+                        pv = reinterpret_cast<const uint32_t *>(in + 9 * cap)[idx];
+                    }
+                }
+                // (A) conservative candidate mask, wave-uniform primitive index
+                const CullRay cr = make_cull_ray(o, d);
+                for (int j = 0; j < a.G; ++j) {
+                    float tn;
+                    const GeomRec &gr = lg[j];
+                    const int type = gr.type;
+                    bool keep = false;
+                    if (type == 1) keep = cull_box(gr.bmin, gr.bmax, cr, tn);
+                    else if (type == 0) keep = cull_sphere(gr.bmin, gr.bmax, cr, tn);
+                    if (keep) mask |= 1u << j;
+                }
+                if (!valid) mask = 0u;
+                // lanes with a non-trivial candidate set step aside
+                const uint32_t bm = mask & boxbits;
+                const bool complex = valid && ((mask & sphbits) != 0u || (bm & (bm - 1u)) != 0u);
+                const u64 cb = __ballot(complex);
+                if (cb) {
+                    if (complex) {
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(cb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cb, 0u));
+                        float *q = ring + ((qhead + qcount + rank) & (kQueueCap - 1u));
+                        q[0 * kQueueCap] = o.x; q[1 * kQueueCap] = o.y; q[2 * kQueueCap] = o.z;
+                        q[3 * kQueueCap] = d.x; q[4 * kQueueCap] = d.y; q[5 * kQueueCap] = d.z;
+                        q[6 * kQueueCap] = thr.x; q[7 * kQueueCap] = thr.y; q[8 * kQueueCap] = thr.z;
+                        q[9 * kQueueCap] = __uint_as_float(pv);
+                        q[10 * kQueueCap] = __uint_as_float(mask);
+                    }
+                    qcount += (uint32_t)__popcll(cb);
+                }
+                valid = valid && !complex;
+            }
+
+            // (B) exact tests on the lane's own candidates: cubes, then spheres, index order, later
+            // candidates re-checked against the best hit; ties to the lower index (reference loop order)
+            bool alive = false;
+            const uint32_t slot = pv >> 24, pixel = pv & 0xFFFFFFu;
+            if (valid) {
+                float best = 100000000000000000.0f;
+                int hit = -1;
+                f3 P = mk(0, 0, 0), N = mk(0, 0, 0);
+                const CullRay cr = make_cull_ray(o, d);
+                for (int pass = 0; pass < 2; ++pass) {
+                    uint32_t m = mask & (pass == 0 ? boxbits : sphbits);
+                    while (m) {
+                        const int j = __builtin_ctz(m);
+                        m &= m - 1u;
+                        const GeomRec *gr = lg + j;
+                        if (hit >= 0) {
+                            float tn;
+                            if (pass == 0) (void)cull_box(gr->bmin, gr->bmax, cr, tn);
+                            else (void)cull_sphere(gr->bmin, gr->bmax, cr, tn);
+                            if (tn - gr->slack > best) continue;
+                        }
+                        f3 p, nn;
+                        const float depth = pass == 0 ? box_test(gr->inv, gr->xf, gr->inside_hits, o, d, p, nn)
+                                                      : sphere_test(gr->inv, gr->xf, o, d, p, nn);
+                        if (depth > -PT_EPSILON && (depth < best || (depth == best && j < hit))) {
+                            best = depth; hit = j; P = p; N = nn;
+                        }
+                    }
+                }
+                if (hit >= 0) {
+                    float *acc = a.batch > 1u ? a.planes + (size_t)slot * a.plane_stride : a.image;
+                    alive = shade_hit<LAST>(lm[lg[hit].mat], P, N, a.bounce, a.iteration + slot, acc, pixel, o, d, thr, emitted);
+                }
+            }
+            const u64 ballot = __ballot(alive);
+            if (!LAST && alive) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
+                const uint32_t oi = base + running + rank;
+                float *out = a.out;
+                out[oi] = o.x; (out + cap)[oi] = o.y; (out + 2 * cap)[oi] = o.z;
+                (out + 3 * cap)[oi] = d.x; (out + 4 * cap)[oi] = d.y; (out + 5 * cap)[oi] = d.z;
+                (out + 6 * cap)[oi] = thr.x; (out + 7 * cap)[oi] = thr.y; (out + 8 * cap)[oi] = thr.z;
+                reinterpret_cast<uint32_t *>(out + 9 * cap)[oi] = pv;
+            }
+            running += (uint32_t)__popcll(ballot);
+        }
+        if (!LAST && lane == 0) a.cnt_out[seg] = running;
+        survivors += running;
+    }
+
+    for (int sft = 32; sft > 0; sft >>= 1) emitted += __shfl_down(emitted, sft);
+    if (lane == 0) {
+        if (survivors) atomicAdd(&ctrl[0], survivors);
+        if (emitted) atomicAdd(&ctrl[1], emitted);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (ctrl[0]) atomicAdd(&bank[a.bounce + 1], ctrl[0]);
+        if (ctrl[1]) atomicAdd(&a.sync->emitted, (u64)ctrl[1]);
+    }
+}
+
 // ------------------------------------------------------------------ fold (batched iterations) ---
 // image[p] = (((image[p] + plane_0[p]) + plane_1[p]) + ...) in iteration order -- the same sum, in the
 // same order, as rendering the iterations one after the other -- and clears the planes for the next
@@ -684,6 +890,13 @@ __global__ void k_hemisphere(int n, const float *nrm, const float *xi, float *ou
     out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
 }
 
+__global__ void k_light_points(const GeomRec *g, int n, const float *seeds, float *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const f3 p = g->type == 0 ? random_point_on_sphere(g->xf, seeds[i]) : random_point_on_cube(g->xf, seeds[i]);
+    out[3 * i] = p.x; out[3 * i + 1] = p.y; out[3 * i + 2] = p.z;
+}
+
 __global__ void k_sincos(int n, const float *a, float *s, float *c) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -714,6 +927,7 @@ struct pt_context {
     uint32_t max_chunks = 0, rpt = 3, status_words = 0;
     bool seg_mode = true;            // wave-autonomous segmented compaction (cfg.compaction == 0)
     bool cull = true;                // AABB candidate culling in front of the exact tests (cfg.culling == 0)
+    bool defer = false;              // sparse-work queue kernel (cfg.ordering == 1; needs LDS geometry, G <= 32)
     uint32_t nseg = 0, seg_slots = 0;     // level 0 (what k_generate fills)
     uint32_t lvl_slots[66] = {0}, lvl_nseg[66] = {0};   // level entering bounce b
     uint32_t *d_segcnt[2] = {nullptr, nullptr};
@@ -873,8 +1087,20 @@ int launch_seg_lc(pt_context *c, const SegArgs &a, bool last, bool gen) {
     return last ? launch_seg_t<LDS, true, CULL, false>(c, a) : launch_seg_t<LDS, false, CULL, false>(c, a);
 }
 
+template <bool LAST, bool GEN>
+int launch_defer_t(pt_context *c, const SegArgs &a) {
+    hipLaunchKernelGGL((k_bounce_defer<LAST, GEN>), dim3(c->grid_bounce), dim3(kBlock), c->lds_bytes, c->stream, a,
+                       (const GeomRec *)c->d_geoms, (const MatRec *)c->d_mats);
+    HIPCHK(hipGetLastError());
+    return PT_OK;
+}
+
 int launch_seg(pt_context *c, const SegArgs &a, bool last, bool gen) {
     Scoped s(c, 1);
+    if (c->defer) {
+        if (gen) return last ? launch_defer_t<true, true>(c, a) : launch_defer_t<false, true>(c, a);
+        return last ? launch_defer_t<true, false>(c, a) : launch_defer_t<false, false>(c, a);
+    }
     if (c->cull) return c->geom_lds ? launch_seg_lc<true, true>(c, a, last, gen) : launch_seg_lc<false, true>(c, a, last, gen);
     return c->geom_lds ? launch_seg_lc<true, false>(c, a, last, gen) : launch_seg_lc<false, false>(c, a, last, gen);
 }
@@ -885,10 +1111,11 @@ int launch_seg(pt_context *c, const SegArgs &a, bool last, bool gen) {
 // segments to occupy every wave, big (batched) launches run best on long ones (measured).
 uint32_t seg_slots_for(const pt_context *c, uint32_t n_rays) {
     if (c->cfg.chunk_rays > 0) return c->seg_slots;
-    const uint32_t slots = (uint32_t)c->grid_bounce * kWaves * 4u;
+    // the sparse-work queue drains once per segment (one partly filled group): longer segments there
+    const uint32_t slots = (uint32_t)c->grid_bounce * kWaves * (c->defer ? 2u : 4u);
     uint32_t S = (((n_rays + slots - 1) / slots) + 63u) & ~63u;
     if (S < 192u) S = 192u;
-    if (S > 1024u) S = 1024u;
+    if (S > (c->defer ? 2048u : 1024u)) S = c->defer ? 2048u : 1024u;
     return S;
 }
 
@@ -1059,11 +1286,13 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     c->n_own = n_own;
     c->seg_mode = (c->cfg.compaction == 0);
     c->cull = (c->cfg.culling == 0) && c->seg_mode;
+    c->defer = c->cull && c->cfg.ordering == 1 && c->cfg.geometry_path == 0 && G <= 32 && c->cfg.mode == 0;
     c->geom_lds = (c->cfg.geometry_path == 0);
 
     // LDS budget: tables (+ the ray stage of the look-back variant)
     uint32_t tb = tables_bytes(G, M, c->geom_lds);
-    const uint32_t stage_bytes = c->seg_mode ? 0u : kBlock * c->rpt * kFields * (uint32_t)sizeof(float);
+    const uint32_t stage_bytes = c->seg_mode ? (c->defer ? kWaves * kQueueCap * kQueueFields * (uint32_t)sizeof(float) : 0u)
+                                             : kBlock * c->rpt * kFields * (uint32_t)sizeof(float);
     if (c->geom_lds && tb + stage_bytes > 160u * 1024u) {   // table too large for LDS: scalar-load path
         c->geom_lds = false;
         tb = tables_bytes(G, M, false);
@@ -1090,7 +1319,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     int per_cu = c->cfg.blocks_per_cu;
     if (per_cu <= 0) {
         int occ = 0;
-        const void *fn = fns[(c->seg_mode ? 4 : 0) + (c->geom_lds ? 0 : 1)];
+        const void *fn = c->defer ? reinterpret_cast<const void *>(&k_bounce_defer<false, false>) : fns[(c->seg_mode ? 4 : 0) + (c->geom_lds ? 0 : 1)];
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, kBlock, c->lds_bytes) != hipSuccess || occ < 1) occ = 2;
         per_cu = occ;
     }
@@ -1406,6 +1635,21 @@ int pt_debug_hemisphere(pt_context *c, int n, const float *normal3, const float 
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(out3, d_o, (size_t)n * 12, hipMemcpyDeviceToHost));
     (void)hipFree(d_n); (void)hipFree(d_x); (void)hipFree(d_o);
+    return PT_OK;
+}
+
+int pt_debug_light_points(pt_context *c, int geom, int n, const float *seeds, float *out3) {
+    if (!c || !c->scene_ready || geom < 0 || geom >= c->G || n < 0 || !seeds || !out3) { pth::set_error("pt_debug_light_points: bad argument"); return PT_ERR_ARGUMENT; }
+    if (n == 0) return PT_OK;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    float *d_s = nullptr, *d_o = nullptr;
+    HIPCHK(hipMalloc(&d_s, (size_t)n * 4)); HIPCHK(hipMalloc(&d_o, (size_t)n * 12));
+    HIPCHK(hipMemcpy(d_s, seeds, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_light_points, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const GeomRec *)(c->d_geoms + geom), n, d_s, d_o);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out3, d_o, (size_t)n * 12, hipMemcpyDeviceToHost));
+    (void)hipFree(d_s); (void)hipFree(d_o);
     return PT_OK;
 }
 

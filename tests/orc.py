@@ -77,6 +77,9 @@ def lib():
     L.orc_box_test.restype = C.c_float; L.orc_box_test.argtypes = [C.POINTER(Geom), C.c_int, f3, f3, f3, f3]
     L.orc_nearest_hit.restype = C.c_int
     L.orc_nearest_hit.argtypes = [C.POINTER(Geom), C.c_int, C.POINTER(Material), f3, f3, f3, f3, f3]
+    L.orc_get_radiuses.restype = None; L.orc_get_radiuses.argtypes = [C.POINTER(Geom), f3]
+    L.orc_random_point_on_cube.restype = None; L.orc_random_point_on_cube.argtypes = [C.POINTER(Geom), C.c_float, f3]
+    L.orc_random_point_on_sphere.restype = None; L.orc_random_point_on_sphere.argtypes = [C.POINTER(Geom), C.c_float, f3]
     L.orc_hemisphere.restype = None; L.orc_hemisphere.argtypes = [f3, C.c_float, C.c_float, f3]
     L.orc_reflection_direction.restype = None; L.orc_reflection_direction.argtypes = [f3, f3, f3]
     L.orc_transmission_direction.restype = C.c_int

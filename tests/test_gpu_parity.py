@@ -175,7 +175,8 @@ def test_accumulation_continues_from_host_image(pt, cornell200):
 
 
 @pytest.mark.parametrize("kw", [dict(geometry_path=1), dict(chunk_rays=64), dict(batch=1), dict(batch=2), dict(batch=3, chunk_rays=100), dict(chunk_rays=64, merge_floor=3000), dict(chunk_rays=64, merge_floor=50, batch=2), dict(chunk_rays=1000), dict(chunk_rays=16, merge_floor=1), dict(chunk_rays=100, merge_floor=7), dict(blocks_per_cu=1),
-                                dict(culling=1), dict(culling=1, geometry_path=1), dict(compaction=1), dict(compaction=1, chunk_rays=256), dict(compaction=1, chunk_rays=1024, geometry_path=1)])
+                                dict(culling=1), dict(culling=1, geometry_path=1), dict(ordering=1), dict(ordering=1, batch=2), dict(ordering=1, chunk_rays=100, merge_floor=7), dict(ordering=1, batch=1, chunk_rays=64),
+                                dict(compaction=1), dict(compaction=1, chunk_rays=256), dict(compaction=1, chunk_rays=1024, geometry_path=1)])
 def test_launch_variants_are_bit_identical(pt, cornell200, kw):
     ref = make_tracer(cornell200)
     ref.set_image(None); ref.render(1, 3)
@@ -184,6 +185,9 @@ def test_launch_variants_are_bit_identical(pt, cornell200, kw):
     assert np.array_equal(ref.image(), var.image())
     n1, a1, p1 = ref.trace_pool(2, 3)
     n2, a2, p2 = var.trace_pool(2, 3)
+    if kw.get("ordering"):            # the sparse-work queue keeps every ray in its segment, not its order in it
+        order = np.argsort(p2, kind="stable")
+        p2, a2 = p2[order], [x[order] for x in a2]
     assert n1 == n2 and np.array_equal(p1, p2) and all(np.array_equal(x, y) for x, y in zip(a1, a2))
 
 
@@ -383,3 +387,36 @@ def test_culling_is_conservative_at_other_scene_scales(pt, name, factor):
     st = tr.stats()
     assert [st.live[k] for k in range(7)] == [int(v) for v in live]
     assert np.array_equal(tr.image(), want)
+
+
+def test_light_sampling_helpers_bit_exact(pt):
+    sc = orc.load_golden_scene("sampleScene").with_resolution(64, 64)
+    tr = make_tracer(sc)
+    seeds = np.arange(1, 4001, dtype=np.float32) * np.float32(7.25)
+    out = (C.c_float * 3)()
+    for gi, fn in ((8, orc.lib().orc_random_point_on_cube), (0, orc.lib().orc_random_point_on_cube), (5, orc.lib().orc_random_point_on_sphere)):
+        got = tr.light_points(gi, seeds)
+        want = np.zeros_like(got)
+        for i, sd in enumerate(seeds):
+            fn(C.byref(sc.geoms[gi]), float(sd), out)
+            want[i] = list(out)
+        assert np.array_equal(got, want, equal_nan=True)
+
+
+@pytest.mark.parametrize("scene_name,depth,iters,kw", [
+    ("sampleScene", 8, 5, dict()), ("cornell_mirror", 8, 4, dict()), ("cornell_glass_4k", 12, 3, dict()),
+    ("cornell_glass_4k", 6, 3, dict(camera_mode=1, antialias=1, aperture=0.25, focal_distance=12.0))])
+def test_sparse_work_queue_ordering_is_bit_identical(pt, scene_name, depth, iters, kw):
+    """ordering=1 (dense regrouping of rays with non-trivial candidate sets): same image, same live
+    counts as the oracle; the pool holds the same rays segment by segment."""
+    sc = orc.load_golden_scene(scene_name).with_resolution(200, 150)
+    tr = make_tracer(sc, depth=depth, ordering=1, **kw)
+    tr.set_image(None); tr.render(1, iters)
+    want, live = orc.render(sc, oracle_config(depth, **kw), 1, iters)
+    st = tr.stats()
+    assert [st.live[k] for k in range(depth + 1)] == [int(v) for v in live]
+    assert np.array_equal(tr.image(), want)
+    n, arrs, pix = tr.trace_pool(2, 3)
+    on, oarrs, opix = orc.trace_pool(sc, oracle_config(depth, **kw), 2, 3)
+    order = np.argsort(pix, kind="stable")
+    assert n == on and np.array_equal(pix[order], opix) and all(np.array_equal(a[order], b) for a, b in zip(arrs, oarrs))

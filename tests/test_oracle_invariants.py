@@ -169,3 +169,36 @@ def test_row_sharding_partitions_the_oracle_render():
         part, l = orc.render(sc, orc.default_config(5, row_offset=r, row_stride=4), 1, 2)
         total += part; lives += l
     assert np.array_equal(total, full) and np.array_equal(lives, live)
+
+
+def test_light_sampling_helpers_follow_the_reference_recipe():
+    """getRadiuses / getRandomPointOnCube / getRandomPointOnSphere (src/intersections.h:207-286, no call
+    sites in the reference): radii of the Cornell light, points on its surface with area-weighted
+    faces, and the sphere sampler's documented defect (NaN when x^2+y^2 > r^2)."""
+    sc = orc.load_golden_scene("sampleScene")
+    light = sc.geoms[8]                       # cube, TRANS 0 10 0, ROTAT 0 0 90, SCALE .3 3 3
+    r = (C.c_float * 3)()
+    L.orc_get_radiuses(C.byref(light), r)
+    np.testing.assert_allclose(list(r), [0.15, 1.5, 1.5], rtol=1e-5)
+    inv = np.array(list(light.inverseTransform), np.float64).reshape(4, 4)
+    out = (C.c_float * 3)()
+    faces = np.zeros(6, int)
+    for seed in range(1, 6001):
+        L.orc_random_point_on_cube(C.byref(light), float(seed), out)
+        p = inv @ np.array([out[0], out[1], out[2], 1.0])
+        assert np.abs(p[:3]).max() == pytest.approx(0.5, abs=1e-4)      # on the surface of the unit cube
+        k = int(np.argmax(np.abs(p[:3])))
+        faces[2 * k + (p[k] < 0)] += 1
+    frac = faces / faces.sum()
+    # faces x+-: 3x3 = 9 each, y+- and z+-: .3x3 = .9 each (object axes), total 21.6
+    assert frac[0] + frac[1] == pytest.approx(18 / 21.6, abs=0.02)
+    sph = sc.geoms[5]
+    nan = 0
+    for seed in range(1, 2001):
+        L.orc_random_point_on_sphere(C.byref(sph), float(seed), out)
+        if np.isnan(out[2]) or np.isnan(out[0]):
+            nan += 1
+        else:
+            d = np.linalg.norm(np.array(list(out)) - np.array([0, 2, 0]))
+            assert d == pytest.approx(1.5, rel=1e-4)
+    assert 0.1 < nan / 2000 < 0.35            # P(x^2+y^2 > 1/4) = 1 - pi/4 = 0.215
