@@ -228,7 +228,7 @@ def main():
                     traffic = round(per_step * args.steps / launches) if per_step else None
                 except Exception:
                     traffic = None
-            roof = {"bound": "hbm", "kernel": "k_bounce (trace + scatter + accumulate + stable compaction)",
+            roof = {"bound": "hbm", "kernel": "k_bounce_defer / k_bounce_seg (cull + exact tests + scatter + accumulate + segmented compaction; bounce 0 also generates)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": round(nbytes / launches), "avg_launch_us": round(avg_ms * 1e3, 2),

@@ -16,9 +16,17 @@ from collections import defaultdict
 
 def short(name):
     import re
-    m = re.search(r"(k_bounce_seg|k_bounce)<(true|false), (true|false)>", name)
+    m = re.search(r"(k_bounce_defer|k_bounce_seg|k_bounce)<([a-z, ]+)>", name)
     if m:
-        return "%s<%s,%s>" % (m.group(1), "lds" if m.group(2) == "true" else "scalar", "last" if m.group(3) == "true" else "mid")
+        flags = [x.strip() == "true" for x in m.group(2).split(",")]
+        if m.group(1) == "k_bounce_defer":
+            return "k_bounce_defer<%s%s>" % ("last" if flags[0] else "mid", ",gen" if flags[1] else "")
+        tag = "%s<%s,%s" % (m.group(1), "lds" if flags[0] else "scalar", "last" if flags[1] else "mid")
+        if len(flags) > 2:
+            tag += ",cull" if flags[2] else ",brute"
+        if len(flags) > 3 and flags[3]:
+            tag += ",gen"
+        return tag + ">"
     for k in ("k_generate", "k_flat", "k_display"):
         if k in name:
             return k
