@@ -221,18 +221,27 @@ def main():
             avg_ms = stats.bounce_ms / launches
             achieved = nbytes / (stats.bounce_ms * 1e-3) / 1e9
             traffic = None
+            valu = None
             tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
             if world == 1 and os.path.exists(tpath):
                 try:
-                    per_step = json.load(open(tpath)).get(args.workload, {}).get("hbm_bytes_per_step")
+                    rec = json.load(open(tpath)).get(args.workload, {})
+                    per_step = rec.get("hbm_bytes_per_step")
                     traffic = round(per_step * args.steps / launches) if per_step else None
+                    vi = rec.get("valu_wave_instructions_per_step")
+                    if vi:
+                        # secondary bound: wave64 VALU issue, 1024 SIMDs x 2.4 GHz / 2 cycles
+                        rate = vi * args.steps / (stats.bounce_ms * 1e-3)
+                        valu = {"wave_instructions_per_step": vi, "achieved_G_wave_inst_per_s": round(rate / 1e9, 1),
+                                "peak_G_wave_inst_per_s": 1228.8, "frac": round(rate / 1.2288e12, 4),
+                                "note": "instruction count from rocprofv3 SQ_INSTS_VALU (profiles/), duration live"}
                 except Exception:
                     traffic = None
             roof = {"bound": "hbm", "kernel": "k_bounce_defer / k_bounce_seg (cull + exact tests + scatter + accumulate + segmented compaction; bounce 0 also generates)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": round(nbytes / launches), "avg_launch_us": round(avg_ms * 1e3, 2),
-                    "launches": launches, "rank0_share_of_frame": round(1.0 / world, 4)}
+                    "launches": launches, "rank0_share_of_frame": round(1.0 / world, 4), "valu_issue": valu}
         result = {
             "metric": "Mray/s (rays launched x bounces / s) at 1080p, 8 bounces" if args.workload != "c2" else "Mray/s (rays launched x bounces / s)",
             "value": round(value, 1), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
