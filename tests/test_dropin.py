@@ -118,3 +118,42 @@ def test_lazy_batching_behind_the_per_iteration_api(tmp_path):
         outs.append(np.fromfile(str(out / "cornell_mirror.0.bmp.f32"), np.float32))
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     assert outs[0].max() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref/dropin_driver not built")
+def test_frame_argument_selects_the_frame(tmp_path):
+    """`frame=1` (src/main.cpp:39-42): the second frame of the scene file is flattened and rendered,
+    the output is named X.1.bmp (src/main.cpp:148-154)."""
+    text = open(os.path.join(ROOT, "scenes", "cornell_mirror.txt")).read()
+    text = text.replace("RES         1920 1080", "RES         48 32").replace("ITERATIONS  1000", "ITERATIONS  2")
+    # move the camera in frame 1 only
+    head, sep, tail = text.partition("frame 1\nEYE         0 4.5 12")
+    assert sep
+    text = head + "frame 1\nEYE         1 4.5 11" + tail
+    p = tmp_path / "two_frames.txt"
+    p.write_text(text)
+    outs = []
+    for frame in (0, 1):
+        env = dict(os.environ, PT_MODE="pathtrace", PT_MAX_DEPTH="4")
+        r = subprocess.run([DRIVER, "scene=" + str(p), "frame=%d" % frame, "out=" + str(tmp_path)], capture_output=True, text=True, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr
+        outs.append(np.fromfile(str(tmp_path / ("cornell_mirror.%d.bmp.f32" % frame)), np.float32))
+    assert not np.array_equal(outs[0], outs[1])
+    pkg = load_package()
+    sf = pkg.SceneFile(str(p))
+    import ctypes as C
+    for frame in (0, 1):
+        geoms, mats, cam = sf.flatten(frame)
+        sc = orc.Scene([], [], orc.Camera())
+        for g in geoms:
+            og = orc.Geom(); og.type, og.materialid = g.type, g.materialid
+            for k in range(12):
+                og.transform[k] = g.transform[k]; og.inverseTransform[k] = g.inverseTransform[k]
+            og.transform[15] = og.inverseTransform[15] = 1.0
+            sc.geoms.append(og)
+        for m in mats:
+            om = orc.Material(); C.memmove(C.byref(om), C.byref(m), 64); sc.materials.append(om)
+        C.memmove(C.byref(sc.camera), C.byref(cam), 52)
+        want, _ = orc.render(sc, orc.default_config(4), 1, 2)
+        assert np.array_equal(outs[frame].reshape(want.shape), want)
