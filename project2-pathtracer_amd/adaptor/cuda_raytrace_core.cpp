@@ -22,7 +22,7 @@
 //   * errors print "Cuda error: <what>: <why>." and exit(EXIT_FAILURE) (raytraceKernel.cu:20-26).
 // Options the reference has no channel for come from the environment:
 //   PT_MODE=pathtrace|reference  PT_MAX_DEPTH  PT_CAMERA_MODE  PT_AA  PT_APERTURE  PT_FOCAL_DIST
-//   PT_DEVICE  PT_PBO_IS_DEVICE  PT_SYNC_EVERY_CALL  PT_LAZY_BATCH
+//   PT_DEVICE  PT_PBO_IS_DEVICE  PT_SYNC_EVERY_CALL  PT_LAZY_BATCH  PT_NGPU  PT_DEVICES
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -36,7 +36,13 @@ static_assert(sizeof(cudaMat4) == 64, "cudaMat4 must be four rows of four floats
 
 namespace {
 
-pt_context *g_ctx = nullptr;
+// One context per GPU (PT_NGPU, default 1; PT_DEVICES="0,1,..." picks the ordinals): the frame's rows
+// are interleaved over them (row y -> context y % N), every pt_render only ENQUEUES work on its own
+// device's stream, so the GPUs run concurrently from this single caller thread; the owned rows are
+// gathered into camera::image when the caller can observe it.  (bench.py uses one process per GPU and an
+// RCCL reduce instead; inside the reference's single-process viewer this is the equivalent.)
+std::vector<pt_context *> g_ctxs;
+#define g_ctx (g_ctxs[0])
 unsigned long long g_scene_hash = 0;
 int g_mode = 0;
 // Lazy batching behind the per-iteration API (PT_LAZY_BATCH=K, headless runs): calls only queue their
@@ -48,10 +54,11 @@ int g_pending_first = 0, g_pending_count = 0;
 
 void flush_pending() {
     if (g_pending_count > 0) {
-        if (pt_render(g_ctx, g_pending_first, g_pending_count) != PT_OK) {
-            fprintf(stderr, "Cuda error: %s: %s.\n", "pt_render", pt_last_error());
-            exit(EXIT_FAILURE);
-        }
+        for (pt_context *c : g_ctxs)
+            if (pt_render(c, g_pending_first, g_pending_count) != PT_OK) {
+                fprintf(stderr, "Cuda error: %s: %s.\n", "pt_render", pt_last_error());
+                exit(EXIT_FAILURE);
+            }
         g_pending_count = 0;
     }
 }
@@ -88,26 +95,62 @@ void rows3(const cudaMat4 &m, float out[12]) {
 // the shim's cudaDeviceReset() (main.cpp:159,171) should call this: drops all device state
 extern "C" void ptmi355_adaptor_reset(void) {
     g_pending_count = 0;
-    if (g_ctx) pt_destroy(g_ctx);
-    g_ctx = nullptr;
+    for (pt_context *c : g_ctxs) pt_destroy(c);
+    g_ctxs.clear();
     g_scene_hash = 0;
 }
 
+namespace {
+
+// camera::image <- the rows each context owns (every context started from the same host image, so a
+// row's owner holds initial value + all of that row's samples)
+void gather_image(float *host, int W, int H) {
+    const size_t N = g_ctxs.size();
+    if (N == 1) {
+        if (pt_get_image(g_ctxs[0], host) != PT_OK) die("Kernel failed!");
+        return;
+    }
+    std::vector<float> tmp((size_t)W * H * 3);
+    for (size_t r = 0; r < N; ++r) {
+        if (pt_get_image(g_ctxs[r], tmp.data()) != PT_OK) die("Kernel failed!");
+        for (int y = (int)r; y < H; y += (int)N)
+            memcpy(host + (size_t)y * W * 3, tmp.data() + (size_t)y * W * 3, (size_t)W * 3 * sizeof(float));
+    }
+}
+
+}  // namespace
+
 void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iterations, material *materials,
                       int numberOfMaterials, geom *geoms, int numberOfGeoms) {
-    if (!g_ctx) {
-        pt_config cfg;
-        pt_config_default(&cfg);
+    if (g_ctxs.empty()) {
         const char *mode = getenv("PT_MODE");
         g_mode = (mode && !strcmp(mode, "reference")) ? 1 : 0;
-        cfg.mode = g_mode;
-        cfg.device = env_int("PT_DEVICE", 0);
-        cfg.max_depth = env_int("PT_MAX_DEPTH", 8);
-        cfg.camera_mode = env_int("PT_CAMERA_MODE", 0);
-        cfg.antialias = env_int("PT_AA", 0);
-        cfg.aperture = env_float("PT_APERTURE", 0.0f);
-        cfg.focal_distance = env_float("PT_FOCAL_DIST", 0.0f);
-        if (pt_create(&cfg, &g_ctx) != PT_OK) die("pt_create");
+        int ngpu = env_int("PT_NGPU", 1);
+        if (ngpu < 1) ngpu = 1;
+        std::vector<int> devices;
+        if (const char *list = getenv("PT_DEVICES")) {
+            for (const char *p = list; *p;) {
+                devices.push_back(atoi(p));
+                while (*p && *p != ',') ++p;
+                if (*p == ',') ++p;
+            }
+        }
+        for (int r = 0; r < ngpu; ++r) {
+            pt_config cfg;
+            pt_config_default(&cfg);
+            cfg.mode = g_mode;
+            cfg.device = r < (int)devices.size() ? devices[r] : env_int("PT_DEVICE", 0) + r;
+            cfg.max_depth = env_int("PT_MAX_DEPTH", 8);
+            cfg.camera_mode = env_int("PT_CAMERA_MODE", 0);
+            cfg.antialias = env_int("PT_AA", 0);
+            cfg.aperture = env_float("PT_APERTURE", 0.0f);
+            cfg.focal_distance = env_float("PT_FOCAL_DIST", 0.0f);
+            cfg.row_offset = r;
+            cfg.row_stride = ngpu;
+            pt_context *c = nullptr;
+            if (pt_create(&cfg, &c) != PT_OK) die("pt_create");
+            g_ctxs.push_back(c);
+        }
     }
 
     // pack the frame exactly as the reference wrapper does (raytraceKernel.cu:179-206)
@@ -134,12 +177,15 @@ void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iteratio
     h = fnv1a(&cam, sizeof cam, h);
     if (h != g_scene_hash) {
         flush_pending();
-        if (pt_upload_scene(g_ctx, pg.data(), numberOfGeoms, reinterpret_cast<const pt_material *>(materials),
-                            numberOfMaterials, &cam) != PT_OK) die("pt_upload_scene");
+        for (pt_context *c : g_ctxs) {
+            if (pt_upload_scene(c, pg.data(), numberOfGeoms, reinterpret_cast<const pt_material *>(materials),
+                                numberOfMaterials, &cam) != PT_OK) die("pt_upload_scene");
+            if (pt_set_image(c, reinterpret_cast<const float *>(renderCam->image)) != PT_OK) die("pt_set_image");
+        }
         g_scene_hash = h;
-        if (pt_set_image(g_ctx, reinterpret_cast<const float *>(renderCam->image)) != PT_OK) die("pt_set_image");
     } else if (iterations == 1) {
-        if (pt_set_image(g_ctx, reinterpret_cast<const float *>(renderCam->image)) != PT_OK) die("pt_set_image");
+        for (pt_context *c : g_ctxs)
+            if (pt_set_image(c, reinterpret_cast<const float *>(renderCam->image)) != PT_OK) die("pt_set_image");
     }
 
     const bool final_call = (unsigned)iterations >= renderCam->iterations;
@@ -150,11 +196,25 @@ void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iteratio
     g_pending_count++;
     if (observable || g_pending_count >= lazy) flush_pending();
 
+    const int W = (int)renderCam->resolution.x, H = (int)renderCam->resolution.y;
+    const bool download = final_call || g_mode == 1 || env_int("PT_SYNC_EVERY_CALL", 0);
     if (PBOpos) {
         const float scale = g_mode == 1 ? 1.0f : 1.0f / (float)iterations;
-        if (pt_display(g_ctx, scale, PBOpos, env_int("PT_PBO_IS_DEVICE", 0)) != PT_OK) die("pt_display");
+        if (g_ctxs.size() == 1) {
+            if (pt_display(g_ctx, scale, PBOpos, env_int("PT_PBO_IS_DEVICE", 0)) != PT_OK) die("pt_display");
+        } else {
+            // several GPUs: gather, then sendImageToPBO on the host (x255, clamp above only, truncate)
+            if (env_int("PT_PBO_IS_DEVICE", 0)) { fprintf(stderr, "Cuda error: pt_display: PT_PBO_IS_DEVICE needs PT_NGPU=1.\n"); exit(EXIT_FAILURE); }
+            std::vector<float> full((size_t)W * H * 3);
+            memcpy(full.data(), renderCam->image, full.size() * sizeof(float));
+            gather_image(full.data(), W, H);
+            for (size_t i = 0; i < (size_t)W * H; ++i) {
+                float c[3];
+                for (int k = 0; k < 3; ++k) { c[k] = (full[3 * i + k] * scale) * 255.0f; if (c[k] > 255.0f) c[k] = 255.0f; }
+                PBOpos[i].w = 0; PBOpos[i].x = (unsigned char)c[0]; PBOpos[i].y = (unsigned char)c[1]; PBOpos[i].z = (unsigned char)c[2];
+            }
+            if (download) memcpy(renderCam->image, full.data(), full.size() * sizeof(float));
+        }
     }
-    if (final_call || g_mode == 1 || env_int("PT_SYNC_EVERY_CALL", 0)) {
-        if (pt_get_image(g_ctx, reinterpret_cast<float *>(renderCam->image)) != PT_OK) die("Kernel failed!");
-    }
+    if (download && !(PBOpos && g_ctxs.size() > 1)) gather_image(reinterpret_cast<float *>(renderCam->image), W, H);
 }

@@ -157,3 +157,24 @@ def test_frame_argument_selects_the_frame(tmp_path):
         C.memmove(C.byref(sc.camera), C.byref(cam), 52)
         want, _ = orc.render(sc, orc.default_config(4), 1, 2)
         assert np.array_equal(outs[frame].reshape(want.shape), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref/dropin_driver not built")
+@pytest.mark.parametrize("ngpu,pbo", [(2, "0"), (3, "1")])
+def test_adaptor_shards_rows_over_several_contexts(tmp_path, ngpu, pbo):
+    """PT_NGPU: the adaptor drives one context per GPU from the reference's single caller thread (rows
+    interleaved, gathered at the observation points).  Exercised here with all contexts on device 0."""
+    scene_path = _small_scene(tmp_path, 64, 48, 5)
+    outs = {}
+    for n in (1, ngpu):
+        out = tmp_path / ("n%d" % n)
+        out.mkdir()
+        env = dict(os.environ, PT_MODE="pathtrace", PT_MAX_DEPTH="5", PT_NGPU=str(n), PT_DEVICES=",".join(["0"] * n), PT_LAZY_BATCH="2")
+        r = subprocess.run([DRIVER, "scene=" + scene_path, "out=" + str(out), "pbo=" + pbo], capture_output=True, text=True, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr
+        outs[n] = (np.fromfile(str(out / "cornell_mirror.0.bmp.f32"), np.float32), (out / "cornell_mirror.0.bmp").read_bytes(),
+                   np.fromfile(str(out / "cornell_mirror.0.bmp.pbo"), np.uint8))
+    assert np.array_equal(outs[1][0], outs[ngpu][0]) and outs[1][1] == outs[ngpu][1]
+    if pbo == "1":
+        assert np.array_equal(outs[1][2], outs[ngpu][2])

@@ -34,6 +34,51 @@ __global__ __launch_bounds__(256) void k(const GeomRec *__restrict__ g, int iter
     out[tid] = acc + o.x;
 }
 
+// the same cube test, but structured like the render kernel's exact pass: 9 primitives staged in LDS,
+// every lane fetches ITS primitive's matrices with a per-lane index (GATHER), optionally only a
+// fraction of the lanes takes part (HALF: every other lane; TENTH: 6 of 64)
+template <int MODE>
+__global__ __launch_bounds__(256) void kg(const GeomRec *__restrict__ g, int iters, float *out) {
+    __shared__ GeomRec lg[9];
+    for (int i = threadIdx.x; i < 9 * (int)(sizeof(GeomRec) / 4); i += 256)
+        reinterpret_cast<uint32_t *>(lg)[i] = reinterpret_cast<const uint32_t *>(g)[i % (sizeof(GeomRec) / 4)];
+    __syncthreads();
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t st = lcg_seed(hash(tid));
+    st = lcg_next(st); float a = u01(st);
+    st = lcg_next(st); float b = u01(st);
+    st = lcg_next(st); float c = u01(st);
+    f3 o = mk(a * 8 - 4, b * 8 + 1, c * 8 - 4 + 12), d = normalize(mk(0.3f - a, 0.4f - b, -1.0f));
+    float acc = 0.0f;
+    const int lane = threadIdx.x & 63;
+    const bool active = MODE == 0 ? true : MODE == 1 ? (lane & 1) == 0 : lane < 6;
+    for (int i = 0; i < iters; ++i) {
+        if (active) {
+            const GeomRec *p = &lg[(lane + i) % 9];
+            f3 P, N;
+            float t = box_test(p->inv, p->xf, 0, o, d, P, N);
+            acc += t;
+            o.x = o.x + t * 1e-7f;
+            d.z = d.z - 1e-9f * acc;
+        }
+    }
+    out[tid] = acc + o.x;
+}
+
+template <int MODE>
+double rung(const GeomRec *dg, float *dout, int blocks, int iters) {
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    hipLaunchKernelGGL(kg<MODE>, dim3(blocks), dim3(256), 0, 0, dg, iters, dout);
+    hipDeviceSynchronize();
+    hipEventRecord(a);
+    hipLaunchKernelGGL(kg<MODE>, dim3(blocks), dim3(256), 0, 0, dg, iters, dout);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    return ms;
+}
+
 template <int KIND>
 double run(const GeomRec *dg, float *dout, int blocks, int iters) {
     hipEvent_t a, b;
@@ -73,6 +118,14 @@ int main() {
             const double wave_instr = tests / 64 * instr[kind];
             printf("{\"kernel\":\"%s\",\"waves_per_simd\":%d,\"ms\":%.3f,\"Gtests_per_s\":%.2f,\"approx_valu_per_test\":%.0f,\"ns_per_wave_instr_per_simd\":%.3f}\n",
                    names[kind], per_cu, ms, tests / ms / 1e6, instr[kind], ms * 1e6 / (wave_instr / 1024));
+        }
+        const char *gn[3] = {"box_test gather all lanes", "box_test gather 32/64 lanes", "box_test gather 6/64 lanes"};
+        for (int mode = 0; mode < 3; ++mode) {
+            const int iters = 2000;
+            const double ms = mode == 0 ? rung<0>(dg, dout, blocks, iters) : mode == 1 ? rung<1>(dg, dout, blocks, iters) : rung<2>(dg, dout, blocks, iters);
+            const double wave_iters = (double)blocks * 4 * iters;          // wave-level loop iterations
+            printf("{\"kernel\":\"%s\",\"waves_per_simd\":%d,\"ms\":%.3f,\"ns_per_wave_iteration_per_simd\":%.1f,\"ns_per_wave_instr_per_simd_at_212\":%.3f}\n",
+                   gn[mode], per_cu, ms, ms * 1e6 / (wave_iters / 1024), ms * 1e6 / (wave_iters * 212 / 1024));
         }
         hipFree(dout);
     }
