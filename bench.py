@@ -47,17 +47,23 @@ def reduce_to_root(tensor, dst=0):
 
 
 def algorithmic_bytes(stats, depth, fused_generate=True):
-    """HBM bytes the trace+scatter+compact launches have to move: every ray
-    entering bounce k >= 1 is read once (40 B) and was written once, compacted, by bounce k-1 (40 B);
-    bounce 0 generates its camera rays in registers (fused generation: nothing read) and the last
-    bounce writes nothing back; every path that ends on an emitter reads+writes its accumulator
-    pixel (24 B).  Geometry/material tables are LDS/L2 traffic = 0.  (With the look-back variant
-    k_generate writes the pool and bounce 0 reads it: that read is counted, the write belongs to
-    k_generate.)"""
+    """Two byte counts for the K timed steps, from the device's live-ray counters:
+
+    survey  -- SURVEY.md section 8(d)'s algorithmic figure, the one the roofline is quoted on:
+               N_0*R (generate write) + sum_k [ N_k*R (read) + N_{k+1}*R (compacted write)
+               + (N_k - N_{k+1})*24 (accumulator read+write of every terminated path) ], R = 40 B.
+    design  -- what THIS implementation has to move: bounce 0 generates its rays in
+               registers (no generate write, no bounce-0 read), the last bounce writes nothing back, and
+               only paths that end on an emitter touch the accumulator.
+    Geometry/material tables are LDS/L2 traffic and count as 0 in both."""
     live = [int(stats.live[k]) for k in range(depth + 1)]
+    survey = live[0] * RAY_BYTES
+    for k in range(depth):
+        survey += live[k] * RAY_BYTES + live[k + 1] * RAY_BYTES + (live[k] - live[k + 1]) * ACCUM_BYTES
     read = sum(live[k] for k in range(0 if not fused_generate else 1, depth)) * RAY_BYTES
     written = sum(live[k] for k in range(1, depth)) * RAY_BYTES
-    return read + written + int(stats.emitted) * ACCUM_BYTES, live
+    design = read + written + int(stats.emitted) * ACCUM_BYTES
+    return survey, design, live
 
 
 def cpu_baseline(scene_path, depth, budget_s=15.0):
@@ -211,7 +217,7 @@ def main():
         elapsed_events = timed_pass(args.warmup + 1, True)
 
     stats = tracer.stats()
-    nbytes, live = algorithmic_bytes(stats, depth, fused_generate=(args.compaction == 0))
+    nbytes, design_bytes, live = algorithmic_bytes(stats, depth, fused_generate=(args.compaction == 0))
     result = None
     if rank == 0:
         value = W * H * args.steps * depth / elapsed / 1e6
@@ -241,6 +247,11 @@ def main():
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": round(nbytes / launches), "avg_launch_us": round(avg_ms * 1e3, 2),
+                    "bytes_formula": "SURVEY.md 8(d): N0*40 + sum_k[N_k*40 + N_k+1*40 + (N_k-N_k+1)*24], from the device live-ray counters",
+                    "design_moved": {"bytes_per_launch": round(design_bytes / launches),
+                                     "achieved": round(design_bytes / (stats.bounce_ms * 1e-3) / 1e9, 1),
+                                     "frac": round(design_bytes / (stats.bounce_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                     "note": "bytes this implementation actually has to move (fused generation, no write-back at the last bounce, accumulator touched by emitter hits only)"},
                     "launches": launches, "rank0_share_of_frame": round(1.0 / world, 4), "valu_issue": valu}
         result = {
             "metric": "Mray/s (rays launched x bounces / s) at 1080p, 8 bounces" if args.workload != "c2" else "Mray/s (rays launched x bounces / s)",
