@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--merge-floor", type=int, default=0)
     ap.add_argument("--ordering", type=int, default=1, help="1 = sparse-work queue (fastest; default here), 0 = stable compaction (the library default)")
+    ap.add_argument("--bvh", type=int, default=0, help="experimental: 1 = per-lane BVH walk, 2 = uniform scan into candidate lists (0 = block-wise culling)")
     ap.add_argument("--batch", type=int, default=0, help="iterations per launch group (0 = auto, 1 = off)")
     ap.add_argument("--resolution", default="", help="WxH override of the scene RES line (experiments only)")
     ap.add_argument("--culling", type=int, default=0, help="0 = AABB candidate culling (default), 1 = brute force")
@@ -167,7 +168,7 @@ def main():
 
     tracer = pkg.PathTracer(pkg.default_config(device=device, max_depth=depth, row_offset=rank, row_stride=world,
                                                geometry_path=args.geometry_path, chunk_rays=args.chunk_rays,
-                                               blocks_per_cu=args.blocks_per_cu, culling=args.culling, merge_floor=args.merge_floor, batch=args.batch, ordering=args.ordering,
+                                               blocks_per_cu=args.blocks_per_cu, culling=args.culling, merge_floor=args.merge_floor, batch=args.batch, ordering=args.ordering, bvh=args.bvh,
                                                compaction=args.compaction))
     tracer.upload(geoms, mats, cam)
     accum = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda:%d" % device)

@@ -106,7 +106,12 @@ typedef struct {
                                 1 = sparse-work queue: rays with non-trivial candidate sets are gathered
                                     into dense wave groups inside their segment (faster; survivors keep
                                     their segment but not their order inside it; results identical) */
-    int   reserved[2];
+    int   bvh;               /* experimental culling structures for <= 256 primitives (both bit-identical, both
+                                measured SLOWER than the default block-wise culling at 256 primitives, see
+                                DESIGN.md): 1 = per-lane BVH walk (LDS nodes, per-lane stack and candidate
+                                lists), 2 = wave-uniform scan of the bounds into per-lane candidate lists;
+                                0 = off */
+    int   reserved[1];
 } pt_config;
 
 typedef struct pt_context pt_context;

@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/ptmi355.h"
@@ -784,6 +785,247 @@ __global__ __launch_bounds__(kBlock, PT_SEG_WAVES) void k_bounce_defer(SegArgs a
     }
 }
 
+// ------------------------------------------------------------------ bounce, BVH culling ---------
+// Many-primitive scenes (33..256 primitives, BASELINE configs[3]): the wave-uniform culling pass of
+// nearest_hit_culled costs ~20 instructions per primitive per ray (5 000 at G = 256).  Here the
+// conservative bounds are organised as a binary BVH (median split, <= 4 primitives per leaf, built on
+// the host at upload) held in LDS next to a 48-byte bound record per primitive; every lane walks it
+// with its own 16-entry stack (LDS, one byte per entry) and appends the primitives whose own bound the
+// ray enters to two per-lane candidate lists (cubes / spheres, 32 one-byte ids each, LDS).  The exact
+// pass then runs list position j of every lane together -- nearest candidate first, later ones
+// re-checked against the best hit -- fetching the matrices from global memory with a per-lane index
+// (the full 144-byte records of 256 primitives would take 37 KB of LDS per block).  A lane whose list
+// overflows makes its wave fall back to the brute-force loop, so the result is always the reference's.
+struct BvhNode {            // 32 B; leaf: a = ~first (negative), b = count; inner: a, b = children
+    float bmin[3]; int a;
+    float bmax[3]; int b;
+};
+struct BoundRec {           // 48 B per primitive (same conservative bound as GeomRec.bmin/bmax)
+    float bmin[4];
+    float bmax[4];
+    int type; float slack; int pad[2];
+};
+constexpr uint32_t kBvhStack = 16, kBvhList = 32;
+
+struct BvhArgs {
+    const BvhNode *nodes; int nnodes;
+    const BoundRec *bounds;
+    const unsigned char *order;   // leaf ranges index into this permutation of the primitives
+    int walk;                     // 1 = per-lane BVH walk, 0 = wave-uniform loop over the bound records
+};
+
+__host__ __device__ inline uint32_t bvh_lds_bytes(int G, int M, int nnodes) {
+    uint32_t b = kCtrlBytes + (((uint32_t)M * sizeof(MatRec) + 15) & ~15u);
+    b += (uint32_t)nnodes * sizeof(BvhNode) + (uint32_t)G * sizeof(BoundRec) + (((uint32_t)G + 15) & ~15u);
+    b += kBlock * (kBvhStack + 2 * kBvhList);
+    return (b + 15) & ~15u;
+}
+
+template <bool LAST, bool GEN>
+__global__ __launch_bounds__(kBlock, PT_SEG_WAVES) void k_bounce_bvh(SegArgs a, BvhArgs bv, const GeomRec *__restrict__ geoms,
+                                                                     const MatRec *__restrict__ mats) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t *ctrl = reinterpret_cast<uint32_t *>(smem);
+    if (threadIdx.x < 2) ctrl[threadIdx.x] = 0u;
+    // LDS: ctrl | materials | nodes | bound records | order | per-thread stack + lists
+    MatRec *lm = reinterpret_cast<MatRec *>(smem + kCtrlBytes);
+    char *cur = smem + kCtrlBytes + (((uint32_t)a.M * sizeof(MatRec) + 15) & ~15u);
+    BvhNode *ln = reinterpret_cast<BvhNode *>(cur); cur += (size_t)bv.nnodes * sizeof(BvhNode);
+    BoundRec *lb = reinterpret_cast<BoundRec *>(cur); cur += (size_t)a.G * sizeof(BoundRec);
+    unsigned char *lo = reinterpret_cast<unsigned char *>(cur); cur += ((uint32_t)a.G + 15) & ~15u;
+    unsigned char *stack = reinterpret_cast<unsigned char *>(cur) + (size_t)threadIdx.x * kBvhStack;
+    unsigned char *lists = reinterpret_cast<unsigned char *>(cur) + (size_t)kBlock * kBvhStack + (size_t)threadIdx.x * 2 * kBvhList;
+    {
+        uint32_t *d0 = reinterpret_cast<uint32_t *>(lm);
+        const uint32_t *s0 = reinterpret_cast<const uint32_t *>(mats);
+        for (uint32_t i = threadIdx.x; i < (uint32_t)a.M * (sizeof(MatRec) / 4); i += kBlock) d0[i] = s0[i];
+        uint32_t *d1 = reinterpret_cast<uint32_t *>(ln);
+        const uint32_t *s1 = reinterpret_cast<const uint32_t *>(bv.nodes);
+        for (uint32_t i = threadIdx.x; i < (uint32_t)bv.nnodes * (sizeof(BvhNode) / 4); i += kBlock) d1[i] = s1[i];
+        uint32_t *d2 = reinterpret_cast<uint32_t *>(lb);
+        const uint32_t *s2 = reinterpret_cast<const uint32_t *>(bv.bounds);
+        for (uint32_t i = threadIdx.x; i < (uint32_t)a.G * (sizeof(BoundRec) / 4); i += kBlock) d2[i] = s2[i];
+        for (uint32_t i = threadIdx.x; i < (uint32_t)a.G; i += kBlock) lo[i] = bv.order[i];
+    }
+    __syncthreads();
+
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t wslot = blockIdx.x * kWaves + wave, nslots = gridDim.x * kWaves;
+    const size_t cap = a.cap;
+    const uint32_t S = a.seg_slots;
+    uint32_t emitted = 0u, survivors = 0u;
+    uint32_t *bank = a.bank ? a.sync->counts_b : a.sync->counts;
+    if (GEN && blockIdx.x == 0 && threadIdx.x < 72) {
+        uint32_t *other = a.bank ? a.sync->counts : a.sync->counts_b;
+        a.sync->totals[threadIdx.x] += other[threadIdx.x];
+        other[threadIdx.x] = 0u;
+        if (threadIdx.x == 0) bank[0] = a.n_rays;
+    }
+
+    for (uint32_t seg = wslot; seg < a.nseg_out; seg += nslots) {
+        const uint32_t sa = a.merge ? 2u * seg : seg;
+        uint32_t na, nb;
+        if (GEN) {
+            const uint32_t f0 = sa * S, f1 = f0 + S;
+            na = f0 >= a.n_rays ? 0u : (a.n_rays - f0 < S ? a.n_rays - f0 : S);
+            nb = (!a.merge || f1 >= a.n_rays) ? 0u : (a.n_rays - f1 < S ? a.n_rays - f1 : S);
+        } else {
+            na = a.cnt_in[sa];
+            nb = (a.merge && sa + 1u < a.nseg_in) ? a.cnt_in[sa + 1u] : 0u;
+        }
+        const uint32_t n = na + nb;
+        const uint32_t base = sa * S;
+        uint32_t running = 0u;
+        for (uint32_t g = 0; g < n; g += 64u) {
+            const uint32_t k = g + lane;
+            const bool valid = k < n;
+            bool alive = false;
+            f3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(0, 0, 0);
+            uint32_t pv = 0u;
+            if (valid) {
+                if (GEN) {
+                    const uint32_t gid = base + (k < na ? k : k - na + S);
+                    const uint32_t slot = a.batch > 1u ? gid / a.n_own : 0u;
+                    const uint32_t local = gid - slot * a.n_own;
+                    const uint32_t W = (uint32_t)a.cam.W;
+                    const uint32_t lr = local / W, x = local - lr * W;
+                    const uint32_t pixel = (lr * (uint32_t)a.cam.row_stride + (uint32_t)a.cam.row_offset) * W + x;
+                    camera_ray(a.cam, pixel, a.iteration + slot, o, d);
+                    thr = mk(1.0f, 1.0f, 1.0f);
+                    pv = pixel | (slot << 24);
+                } else {
+                    const uint32_t idx = base + (k < na ? k : k - na + S);
+                    const float *in = a.in;
+                    o = mk(in[idx], (in + cap)[idx], (in + 2 * cap)[idx]);
+                    d = mk((in + 3 * cap)[idx], (in + 4 * cap)[idx], (in + 5 * cap)[idx]);
+                    thr = mk((in + 6 * cap)[idx], (in + 7 * cap)[idx], (in + 8 * cap)[idx]);
+                    pv = reinterpret_cast<const uint32_t *>(in + 9 * cap)[idx];
+                }
+            }
+            const uint32_t slot = pv >> 24, pixel = pv & 0xFFFFFFu;
+
+            // (A) per-lane BVH walk -> candidate lists
+            const CullRay cr = make_cull_ray(o, d);
+            uint32_t cnt0 = 0u, cnt1 = 0u, near0 = 0u, near1 = 0u;     // list lengths, position of the nearest entry
+            float nt0 = 3.0e38f, nt1 = 3.0e38f;
+            bool overflow = false;
+            if (bv.walk == 0) {
+                // flat variant: wave-uniform loop over all bound records (broadcast LDS reads, no divergence),
+                // candidates appended to the same per-lane lists
+                for (int p = 0; p < a.G; ++p) {
+                    const BoundRec &br = lb[p];
+                    float tp;
+                    if (br.type == 1) {
+                        if (valid && cull_box(br.bmin, br.bmax, cr, tp)) {
+                            if (cnt0 < kBvhList) { lists[cnt0] = (unsigned char)p; if (tp < nt0) { nt0 = tp; near0 = cnt0; } cnt0++; } else overflow = true;
+                        }
+                    } else if (br.type == 0) {
+                        if (valid && cull_sphere(br.bmin, br.bmax, cr, tp)) {
+                            if (cnt1 < kBvhList) { lists[kBvhList + cnt1] = (unsigned char)p; if (tp < nt1) { nt1 = tp; near1 = cnt1; } cnt1++; } else overflow = true;
+                        }
+                    }
+                }
+            } else if (valid) {
+                uint32_t node = 0u, sp = 0u;
+                for (;;) {
+                    const BvhNode nd = ln[node];
+                    float tn;
+                    if (cull_box(nd.bmin, nd.bmax, cr, tn)) {
+                        if (nd.a >= 0) {                              // inner node: descend left, remember right
+                            if (sp < kBvhStack) stack[sp++] = (unsigned char)nd.b; else overflow = true;
+                            node = (uint32_t)nd.a;
+                            continue;
+                        }
+                        const uint32_t first = (uint32_t)~nd.a;
+                        for (int i = 0; i < nd.b; ++i) {
+                            const uint32_t p = lo[first + i];
+                            const BoundRec &br = lb[p];
+                            float tp;
+                            if (br.type == 1) {
+                                if (cull_box(br.bmin, br.bmax, cr, tp)) {
+                                    if (cnt0 < kBvhList) { lists[cnt0] = (unsigned char)p; if (tp < nt0) { nt0 = tp; near0 = cnt0; } cnt0++; } else overflow = true;
+                                }
+                            } else if (br.type == 0) {
+                                if (cull_sphere(br.bmin, br.bmax, cr, tp)) {
+                                    if (cnt1 < kBvhList) { lists[kBvhList + cnt1] = (unsigned char)p; if (tp < nt1) { nt1 = tp; near1 = cnt1; } cnt1++; } else overflow = true;
+                                }
+                            }
+                        }
+                    }
+                    if (sp == 0u) break;
+                    node = stack[--sp];
+                }
+            }
+            if (valid) {
+                // nearest candidate to the front of its list
+                if (cnt0 > 1u && near0 != 0u) { const unsigned char t0 = lists[0]; lists[0] = lists[near0]; lists[near0] = t0; }
+                if (cnt1 > 1u && near1 != 0u) { const unsigned char t1 = lists[kBvhList]; lists[kBvhList] = lists[kBvhList + near1]; lists[kBvhList + near1] = t1; }
+            }
+
+            // (B) exact tests, list position j of every lane together
+            if (valid) {
+                float best = 100000000000000000.0f;
+                int hit = -1;
+                f3 P = mk(0, 0, 0), N = mk(0, 0, 0);
+                if (__any(overflow)) {                               // rare: this wave takes the reference loop
+                    float t;
+                    hit = nearest_hit(geoms, a.G, o, d, t, P, N);
+                } else {
+                    for (int pass = 0; pass < 2; ++pass) {
+                        const uint32_t cnt = pass == 0 ? cnt0 : cnt1;
+                        const unsigned char *lst = lists + pass * kBvhList;
+                        for (uint32_t j = 0; j < cnt; ++j) {
+                            const int p = lst[j];
+                            if (hit >= 0) {
+                                const BoundRec &br = lb[p];
+                                float tn;
+                                if (pass == 0) (void)cull_box(br.bmin, br.bmax, cr, tn);
+                                else (void)cull_sphere(br.bmin, br.bmax, cr, tn);
+                                if (tn - br.slack > best) continue;
+                            }
+                            const GeomRec *gr = geoms + p;                // per-lane gather from global (L1/L2)
+                            f3 pp, nn;
+                            const float depth = pass == 0 ? box_test(gr->inv, gr->xf, gr->inside_hits, o, d, pp, nn)
+                                                          : sphere_test(gr->inv, gr->xf, o, d, pp, nn);
+                            if (depth > -PT_EPSILON && (depth < best || (depth == best && p < hit))) {
+                                best = depth; hit = p; P = pp; N = nn;
+                            }
+                        }
+                    }
+                }
+                if (hit >= 0) {
+                    float *acc = a.batch > 1u ? a.planes + (size_t)slot * a.plane_stride : a.image;
+                    alive = shade_hit<LAST>(lm[geoms[hit].mat], P, N, a.bounce, a.iteration + slot, acc, pixel, o, d, thr, emitted);
+                }
+            }
+            const u64 ballot = __ballot(alive);
+            if (!LAST && alive) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
+                const uint32_t oi = base + running + rank;
+                float *out = a.out;
+                out[oi] = o.x; (out + cap)[oi] = o.y; (out + 2 * cap)[oi] = o.z;
+                (out + 3 * cap)[oi] = d.x; (out + 4 * cap)[oi] = d.y; (out + 5 * cap)[oi] = d.z;
+                (out + 6 * cap)[oi] = thr.x; (out + 7 * cap)[oi] = thr.y; (out + 8 * cap)[oi] = thr.z;
+                reinterpret_cast<uint32_t *>(out + 9 * cap)[oi] = pv;
+            }
+            running += (uint32_t)__popcll(ballot);
+        }
+        if (!LAST && lane == 0) a.cnt_out[seg] = running;
+        survivors += running;
+    }
+
+    for (int sft = 32; sft > 0; sft >>= 1) emitted += __shfl_down(emitted, sft);
+    if (lane == 0) {
+        if (survivors) atomicAdd(&ctrl[0], survivors);
+        if (emitted) atomicAdd(&ctrl[1], emitted);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (ctrl[0]) atomicAdd(&bank[a.bounce + 1], ctrl[0]);
+        if (ctrl[1]) atomicAdd(&a.sync->emitted, (u64)ctrl[1]);
+    }
+}
+
 // ------------------------------------------------------------------ fold (batched iterations) ---
 // image[p] = (((image[p] + plane_0[p]) + plane_1[p]) + ...) in iteration order -- the same sum, in the
 // same order, as rendering the iterations one after the other -- and clears the planes for the next
@@ -928,6 +1170,9 @@ struct pt_context {
     bool seg_mode = true;            // wave-autonomous segmented compaction (cfg.compaction == 0)
     bool cull = true;                // AABB candidate culling in front of the exact tests (cfg.culling == 0)
     bool defer = false;              // sparse-work queue kernel (cfg.ordering == 1; needs LDS geometry, G <= 32)
+    bool use_bvh = false;            // candidate-list kernel (cfg.bvh 1 = BVH walk, 2 = uniform scan; <= 256 primitives)
+    BvhNode *d_nodes = nullptr; BoundRec *d_bounds = nullptr; unsigned char *d_order = nullptr;
+    int nnodes = 0;
     uint32_t nseg = 0, seg_slots = 0;     // level 0 (what k_generate fills)
     uint32_t lvl_slots[66] = {0}, lvl_nseg[66] = {0};   // level entering bounce b
     uint32_t *d_segcnt[2] = {nullptr, nullptr};
@@ -1000,6 +1245,10 @@ void free_scene_buffers(pt_context *c) {
     for (int i = 0; i < 2; ++i) { if (c->d_segcnt[i]) (void)hipFree(c->d_segcnt[i]); c->d_segcnt[i] = nullptr; }
     if (c->d_planes) (void)hipFree(c->d_planes);
     c->d_planes = nullptr;
+    if (c->d_nodes) (void)hipFree(c->d_nodes);
+    if (c->d_bounds) (void)hipFree(c->d_bounds);
+    if (c->d_order) (void)hipFree(c->d_order);
+    c->d_nodes = nullptr; c->d_bounds = nullptr; c->d_order = nullptr;
     if (c->image == c->image_own) c->image = nullptr;
     c->image_own = nullptr; c->d_geoms = nullptr; c->d_mats = nullptr; c->d_status = nullptr; c->d_display = nullptr;
     c->scene_ready = false;
@@ -1059,6 +1308,54 @@ void world_bounds(const pt_geom &src, GeomRec *dst) {
     dst->slack = src.type == 0 ? (float)(1.5e-4 * maxrow + 1e-5) : 1e-5f;
 }
 
+// median-split BVH over the primitives' conservative bounds (<= 4 per leaf)
+struct BvhBuild {
+    std::vector<BvhNode> nodes;
+    std::vector<unsigned char> order;
+    std::vector<float> lo, hi;       // 3 floats per primitive
+    int build(int first, int count) {
+        const int id = (int)nodes.size();
+        nodes.emplace_back();
+        float bmin[3] = {3e38f, 3e38f, 3e38f}, bmax[3] = {-3e38f, -3e38f, -3e38f};
+        for (int i = first; i < first + count; ++i)
+            for (int k = 0; k < 3; ++k) {
+                bmin[k] = std::fmin(bmin[k], lo[3 * order[i] + k]);
+                bmax[k] = std::fmax(bmax[k], hi[3 * order[i] + k]);
+            }
+        for (int k = 0; k < 3; ++k) { nodes[id].bmin[k] = bmin[k]; nodes[id].bmax[k] = bmax[k]; }
+        if (count <= 4) { nodes[id].a = ~first; nodes[id].b = count; return id; }
+        int axis = 0;
+        float ext = -1.0f;
+        for (int k = 0; k < 3; ++k) {            // split the axis with the widest spread of centres
+            float cmin = 3e38f, cmax = -3e38f;
+            for (int i = first; i < first + count; ++i) {
+                const float cc = 0.5f * (lo[3 * order[i] + k] + hi[3 * order[i] + k]);
+                cmin = std::fmin(cmin, cc); cmax = std::fmax(cmax, cc);
+            }
+            if (cmax - cmin > ext) { ext = cmax - cmin; axis = k; }
+        }
+        std::sort(order.begin() + first, order.begin() + first + count, [&](unsigned char x, unsigned char y) {
+            return lo[3 * x + axis] + hi[3 * x + axis] < lo[3 * y + axis] + hi[3 * y + axis];
+        });
+        const int half = count / 2;
+        const int l = build(first, half);
+        const int r = build(first + half, count - half);
+        nodes[id].a = l; nodes[id].b = r;
+        return id;
+    }
+};
+
+template <bool LAST, bool GEN>
+int launch_bvh_t(pt_context *c, const SegArgs &a) {
+    BvhArgs bv;
+    bv.nodes = c->d_nodes; bv.nnodes = c->nnodes; bv.bounds = c->d_bounds; bv.order = c->d_order;
+    bv.walk = c->cfg.bvh == 1 ? 1 : 0;
+    hipLaunchKernelGGL((k_bounce_bvh<LAST, GEN>), dim3(c->grid_bounce), dim3(kBlock), c->lds_bytes, c->stream, a, bv,
+                       (const GeomRec *)c->d_geoms, (const MatRec *)c->d_mats);
+    HIPCHK(hipGetLastError());
+    return PT_OK;
+}
+
 template <bool LDS, bool LAST>
 int launch_bounce_t(pt_context *c, const BounceArgs &a) {
     hipLaunchKernelGGL((k_bounce<LDS, LAST>), dim3(c->grid_bounce), dim3(kBlock), c->lds_bytes, c->stream, a,
@@ -1097,6 +1394,10 @@ int launch_defer_t(pt_context *c, const SegArgs &a) {
 
 int launch_seg(pt_context *c, const SegArgs &a, bool last, bool gen) {
     Scoped s(c, 1);
+    if (c->use_bvh) {
+        if (gen) return last ? launch_bvh_t<true, true>(c, a) : launch_bvh_t<false, true>(c, a);
+        return last ? launch_bvh_t<true, false>(c, a) : launch_bvh_t<false, false>(c, a);
+    }
     if (c->defer) {
         if (gen) return last ? launch_defer_t<true, true>(c, a) : launch_defer_t<false, true>(c, a);
         return last ? launch_defer_t<true, false>(c, a) : launch_defer_t<false, false>(c, a);
@@ -1287,7 +1588,36 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     c->seg_mode = (c->cfg.compaction == 0);
     c->cull = (c->cfg.culling == 0) && c->seg_mode;
     c->defer = c->cull && c->cfg.ordering == 1 && c->cfg.geometry_path == 0 && G <= 32 && c->cfg.mode == 0;
+    c->use_bvh = c->cull && c->cfg.mode == 0 && G <= 256 && (c->cfg.bvh == 1 || c->cfg.bvh == 2);   // opt-in: measured slower than block-wise culling
+    if (c->use_bvh) c->defer = false;
     c->geom_lds = (c->cfg.geometry_path == 0);
+
+    if (c->use_bvh) {
+        BvhBuild bb;
+        bb.order.resize(G); bb.lo.resize(3 * G); bb.hi.resize(3 * G);
+        std::vector<BoundRec> br(G);
+        for (int i = 0; i < G; ++i) {
+            bb.order[i] = (unsigned char)i;
+            memcpy(br[i].bmin, g[i].bmin, 16); memcpy(br[i].bmax, g[i].bmax, 16);
+            br[i].type = g[i].type; br[i].slack = g[i].slack; br[i].pad[0] = br[i].pad[1] = 0;
+            for (int k = 0; k < 3; ++k) {
+                if (g[i].type == 0) { bb.lo[3 * i + k] = g[i].bmin[k] - g[i].bmax[3]; bb.hi[3 * i + k] = g[i].bmin[k] + g[i].bmax[3]; }
+                else if (g[i].type == 1) { bb.lo[3 * i + k] = g[i].bmin[k]; bb.hi[3 * i + k] = g[i].bmax[k]; }
+                else { bb.lo[3 * i + k] = 0.0f; bb.hi[3 * i + k] = 0.0f; }      // MESH: never a candidate (type check in the leaf)
+            }
+        }
+        bb.build(0, G);
+        c->nnodes = (int)bb.nodes.size();
+        if (c->nnodes > 255) { c->use_bvh = false; }                 // stack entries are one byte
+        else {
+            HIPCHK(hipMalloc(&c->d_nodes, bb.nodes.size() * sizeof(BvhNode)));
+            HIPCHK(hipMalloc(&c->d_bounds, (size_t)G * sizeof(BoundRec)));
+            HIPCHK(hipMalloc(&c->d_order, (size_t)G));
+            HIPCHK(hipMemcpy(c->d_nodes, bb.nodes.data(), bb.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(c->d_bounds, br.data(), (size_t)G * sizeof(BoundRec), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(c->d_order, bb.order.data(), (size_t)G, hipMemcpyHostToDevice));
+        }
+    }
 
     // LDS budget: tables (+ the ray stage of the look-back variant)
     uint32_t tb = tables_bytes(G, M, c->geom_lds);
@@ -1297,7 +1627,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         c->geom_lds = false;
         tb = tables_bytes(G, M, false);
     }
-    c->lds_bytes = tb + stage_bytes;
+    c->lds_bytes = c->use_bvh ? bvh_lds_bytes(G, M, c->nnodes) : tb + stage_bytes;
     const void *fns[8] = {
         reinterpret_cast<const void *>(&k_bounce<true, false>), reinterpret_cast<const void *>(&k_bounce<false, false>),
         reinterpret_cast<const void *>(&k_bounce<true, true>), reinterpret_cast<const void *>(&k_bounce<false, true>),
@@ -1319,7 +1649,8 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     int per_cu = c->cfg.blocks_per_cu;
     if (per_cu <= 0) {
         int occ = 0;
-        const void *fn = c->defer ? reinterpret_cast<const void *>(&k_bounce_defer<false, false>) : fns[(c->seg_mode ? 4 : 0) + (c->geom_lds ? 0 : 1)];
+        const void *fn = c->use_bvh ? reinterpret_cast<const void *>(&k_bounce_bvh<false, false>)
+                       : c->defer ? reinterpret_cast<const void *>(&k_bounce_defer<false, false>) : fns[(c->seg_mode ? 4 : 0) + (c->geom_lds ? 0 : 1)];
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, kBlock, c->lds_bytes) != hipSuccess || occ < 1) occ = 2;
         per_cu = occ;
     }

@@ -175,7 +175,7 @@ def test_accumulation_continues_from_host_image(pt, cornell200):
 
 
 @pytest.mark.parametrize("kw", [dict(geometry_path=1), dict(chunk_rays=64), dict(batch=1), dict(batch=2), dict(batch=3, chunk_rays=100), dict(chunk_rays=64, merge_floor=3000), dict(chunk_rays=64, merge_floor=50, batch=2), dict(chunk_rays=1000), dict(chunk_rays=16, merge_floor=1), dict(chunk_rays=100, merge_floor=7), dict(blocks_per_cu=1),
-                                dict(culling=1), dict(culling=1, geometry_path=1), dict(ordering=1), dict(ordering=1, batch=2), dict(ordering=1, chunk_rays=100, merge_floor=7), dict(ordering=1, batch=1, chunk_rays=64),
+                                dict(culling=1), dict(culling=1, geometry_path=1), dict(bvh=1), dict(bvh=1, batch=3, chunk_rays=64), dict(ordering=1), dict(ordering=1, batch=2), dict(ordering=1, chunk_rays=100, merge_floor=7), dict(ordering=1, batch=1, chunk_rays=64),
                                 dict(compaction=1), dict(compaction=1, chunk_rays=256), dict(compaction=1, chunk_rays=1024, geometry_path=1)])
 def test_launch_variants_are_bit_identical(pt, cornell200, kw):
     ref = make_tracer(cornell200)
@@ -268,7 +268,7 @@ def test_full_size_properties_1080p(pt):
     assert np.array_equal(got[rows], a[rows])
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(geometry_path=1), dict(culling=1)])
+@pytest.mark.parametrize("kw", [dict(), dict(bvh=1), dict(bvh=2), dict(geometry_path=1), dict(culling=1), dict(bvh=1, batch=2, chunk_rays=100)])
 def test_many_primitives_scene_matches_oracle(pt, kw):
     """BASELINE config 4's scene (256 spheres+cubes incl. rotated cubes, mirrors, glass): the
     candidate culling must never change the nearest hit."""
