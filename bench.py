@@ -122,7 +122,7 @@ def main():
     ap.add_argument("--chunk-rays", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--merge-floor", type=int, default=0)
-    ap.add_argument("--ordering", type=int, default=1, help="1 = sparse-work queue (fastest; default here), 0 = stable compaction (the library default)")
+    ap.add_argument("--ordering", type=int, default=1, help="0 = stable compaction (library default), 1 = sparse-work queue, 2 = binned two-ended compaction")
     ap.add_argument("--bvh", type=int, default=0, help="experimental: 1 = per-lane BVH walk, 2 = uniform scan into candidate lists (0 = block-wise culling)")
     ap.add_argument("--batch", type=int, default=0, help="iterations per launch group (0 = auto, 1 = off)")
     ap.add_argument("--resolution", default="", help="WxH override of the scene RES line (experiments only)")
@@ -262,7 +262,7 @@ def main():
             "config": {"workload": desc, "scene": scene_path, "resolution": [W, H], "bounces": depth,
                        "rays_per_step": W * H, "sharding": "rows interleaved over %d GPU(s), 1 RCCL reduce per frame" % world,
                        "live_ray_bounces_per_step": round(sum(live[:depth]) / max(1, int(stats.iterations))),
-                       "compaction": ("segmented, wave-autonomous; " + ("sparse-work queue (ordering=1)" if args.ordering == 1 else "stable order (ordering=0)")) if args.compaction == 0 else "global look-back scan",
+                       "compaction": ("segmented, wave-autonomous; " + {0: "stable order (ordering=0)", 1: "sparse-work queue (ordering=1)", 2: "binned two-ended (ordering=2)"}[args.ordering]) if args.compaction == 0 else "global look-back scan",
                        "ms_per_step_with_kernel_events": round(elapsed_events / args.steps * 1e3, 4) if elapsed_events else None},
             "roofline": roof,
         }

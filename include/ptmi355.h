@@ -105,7 +105,10 @@ typedef struct {
     int   ordering;          /* 0 = stable: the compacted stream keeps generation order (default)
                                 1 = sparse-work queue: rays with non-trivial candidate sets are gathered
                                     into dense wave groups inside their segment (faster; survivors keep
-                                    their segment but not their order inside it; results identical) */
+                                    their segment but not their order inside it; results identical)
+                                2 = binned: every scattered ray is classified by the culling pass of its NEW
+                                    direction and written to the front (trivial candidate set) or the back of
+                                    its segment; the candidate mask travels with the ray */
     int   bvh;               /* experimental culling structures for <= 256 primitives (both bit-identical, both
                                 measured SLOWER than the default block-wise culling at 256 primitives, see
                                 DESIGN.md): 1 = per-lane BVH walk (LDS nodes, per-lane stack and candidate

@@ -39,6 +39,7 @@ constexpr int kBlock = 256;          // 4 waves
 #endif
 constexpr int kWaves = kBlock / 64;
 constexpr int kFields = 10;          // ox oy oz dx dy dz tr tg tb pixel
+constexpr int kPoolFields = 11;      // + candidate mask (binned ordering only)
 constexpr uint32_t kSpinLimit = 1u << 22;
 
 typedef unsigned long long u64;
@@ -477,6 +478,7 @@ struct SegArgs {
     float *planes;                   // batch > 1: one accumulator plane per in-flight iteration slot
     size_t plane_stride;             //   (floats); folded into the image in iteration order afterwards
     uint32_t bank;                   // counter bank of this launch group (the host alternates 0/1)
+    uint32_t bin1_offset;            // binned ordering: bin-1 counts live at cnt[bin1_offset + seg]
     CamRec cam;
 };
 
@@ -771,6 +773,174 @@ __global__ __launch_bounds__(kBlock, PT_SEG_WAVES) void k_bounce_defer(SegArgs a
         }
         if (!LAST && lane == 0) a.cnt_out[seg] = running;
         survivors += running;
+    }
+
+    for (int sft = 32; sft > 0; sft >>= 1) emitted += __shfl_down(emitted, sft);
+    if (lane == 0) {
+        if (survivors) atomicAdd(&ctrl[0], survivors);
+        if (emitted) atomicAdd(&ctrl[1], emitted);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (ctrl[0]) atomicAdd(&bank[a.bounce + 1], ctrl[0]);
+        if (ctrl[1]) atomicAdd(&a.sync->emitted, (u64)ctrl[1]);
+    }
+}
+
+// ------------------------------------------------------------------ bounce, binned ordering -----
+// `ordering = 2`.  The sparse-work queue regroups rays AFTER they turned out to need several exact
+// tests; this variant sorts them BEFORE: when a ray is scattered, its NEW direction is run through the
+// conservative culling pass right away, the candidate mask travels with the ray (11th pool field) and
+// the survivor is written to the FRONT of its segment if the mask is trivial (no sphere candidate, at
+// most one cube candidate) and to the BACK otherwise (two-ended compaction, counts c0 / c1).  The next
+// bounce reads the two runs as two dense lists: front groups need exactly one exact cube test per
+// lane, back groups run the general loop with all lanes busy.  Same number of culling passes per ray
+// as before (one per bounce, just moved to the producer), no LDS ring, no partly filled drain groups.
+// Survivors keep their segment, not their order inside it; results identical.
+__device__ __forceinline__ uint32_t cull_mask(const GeomRec *lg, int G, f3 o, f3 d) {
+    const CullRay cr = make_cull_ray(o, d);
+    uint32_t mask = 0u;
+    for (int j = 0; j < G; ++j) {
+        float tn;
+        const GeomRec &gr = lg[j];
+        const int type = gr.type;
+        bool keep = false;
+        if (type == 1) keep = cull_box(gr.bmin, gr.bmax, cr, tn);
+        else if (type == 0) keep = cull_sphere(gr.bmin, gr.bmax, cr, tn);
+        if (keep) mask |= 1u << j;
+    }
+    return mask;
+}
+
+template <bool LAST, bool GEN>
+__global__ __launch_bounds__(kBlock, PT_SEG_WAVES) void k_bounce_bin(SegArgs a, const GeomRec *__restrict__ geoms,
+                                                                     const MatRec *__restrict__ mats) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t *ctrl = reinterpret_cast<uint32_t *>(smem);
+    if (threadIdx.x < 2) ctrl[threadIdx.x] = 0u;
+    GeomRec *lg;
+    MatRec *lm;
+    stage_tables(smem, geoms, a.G, mats, a.M, true, lg, lm);
+
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t wslot = blockIdx.x * kWaves + wave, nslots = gridDim.x * kWaves;
+    const size_t cap = a.cap;
+    const uint32_t S = a.seg_slots;
+    uint32_t emitted = 0u, survivors = 0u;
+    uint32_t *bank = a.bank ? a.sync->counts_b : a.sync->counts;
+    if (GEN && blockIdx.x == 0 && threadIdx.x < 72) {
+        uint32_t *other = a.bank ? a.sync->counts : a.sync->counts_b;
+        a.sync->totals[threadIdx.x] += other[threadIdx.x];
+        other[threadIdx.x] = 0u;
+        if (threadIdx.x == 0) bank[0] = a.n_rays;
+    }
+    uint32_t boxbits = 0u, sphbits = 0u;
+    for (int j = 0; j < a.G; ++j) {
+        const int type = lg[j].type;
+        if (type == 1) boxbits |= 1u << j;
+        else if (type == 0) sphbits |= 1u << j;
+    }
+
+    for (uint32_t seg = wslot; seg < a.nseg_out; seg += nslots) {
+        const uint32_t base = seg * S;
+        uint32_t c0, c1;
+        if (GEN) {
+            c0 = base >= a.n_rays ? 0u : (a.n_rays - base < S ? a.n_rays - base : S);
+            c1 = 0u;
+        } else {
+            c0 = a.cnt_in[seg];
+            c1 = a.cnt_in[a.bin1_offset + seg];
+        }
+        uint32_t run0 = 0u, run1 = 0u;
+        for (int list = 0; list < 2; ++list) {
+            const uint32_t n = list == 0 ? c0 : c1;
+            for (uint32_t g = 0; g < n; g += 64u) {
+                const uint32_t k = g + lane;
+                const bool valid = k < n;
+                f3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(0, 0, 0);
+                uint32_t pv = 0u, mask = 0u;
+                if (valid) {
+                    if (GEN) {
+                        const uint32_t gid = base + k;
+                        const uint32_t slot = a.batch > 1u ? gid / a.n_own : 0u;
+                        const uint32_t local = gid - slot * a.n_own;
+                        const uint32_t W = (uint32_t)a.cam.W;
+                        const uint32_t lr = local / W, x = local - lr * W;
+                        const uint32_t pixel = (lr * (uint32_t)a.cam.row_stride + (uint32_t)a.cam.row_offset) * W + x;
+                        camera_ray(a.cam, pixel, a.iteration + slot, o, d);
+                        thr = mk(1.0f, 1.0f, 1.0f);
+                        pv = pixel | (slot << 24);
+                    } else {
+                        const uint32_t idx = list == 0 ? base + k : base + S - 1u - k;
+                        const float *in = a.in;
+                        o = mk(in[idx], (in + cap)[idx], (in + 2 * cap)[idx]);
+                        d = mk((in + 3 * cap)[idx], (in + 4 * cap)[idx], (in + 5 * cap)[idx]);
+                        thr = mk((in + 6 * cap)[idx], (in + 7 * cap)[idx], (in + 8 * cap)[idx]);
+                        pv = reinterpret_cast<const uint32_t *>(in + 9 * cap)[idx];
+                        mask = reinterpret_cast<const uint32_t *>(in + 10 * cap)[idx];
+                    }
+                }
+                if (GEN) mask = valid ? cull_mask(lg, a.G, o, d) : 0u;
+                const uint32_t slot = pv >> 24, pixel = pv & 0xFFFFFFu;
+
+                bool alive = false;
+                if (valid) {
+                    float best = 100000000000000000.0f;
+                    int hit = -1;
+                    f3 P = mk(0, 0, 0), N = mk(0, 0, 0);
+                    const CullRay cr = make_cull_ray(o, d);
+                    for (int pass = 0; pass < 2; ++pass) {
+                        uint32_t m = mask & (pass == 0 ? boxbits : sphbits);
+                        while (m) {
+                            const int j = __builtin_ctz(m);
+                            m &= m - 1u;
+                            const GeomRec *gr = lg + j;
+                            if (hit >= 0) {
+                                float tn;
+                                if (pass == 0) (void)cull_box(gr->bmin, gr->bmax, cr, tn);
+                                else (void)cull_sphere(gr->bmin, gr->bmax, cr, tn);
+                                if (tn - gr->slack > best) continue;
+                            }
+                            f3 pp, nn;
+                            const float depth = pass == 0 ? box_test(gr->inv, gr->xf, gr->inside_hits, o, d, pp, nn)
+                                                          : sphere_test(gr->inv, gr->xf, o, d, pp, nn);
+                            if (depth > -PT_EPSILON && (depth < best || (depth == best && j < hit))) {
+                                best = depth; hit = j; P = pp; N = nn;
+                            }
+                        }
+                    }
+                    if (hit >= 0) {
+                        float *acc = a.batch > 1u ? a.planes + (size_t)slot * a.plane_stride : a.image;
+                        alive = shade_hit<LAST>(lm[lg[hit].mat], P, N, a.bounce, a.iteration + slot, acc, pixel, o, d, thr, emitted);
+                    }
+                }
+                if (LAST) {
+                    run0 += (uint32_t)__popcll(__ballot(alive));
+                } else {
+                    // classify the NEW ray for the next bounce, then two-ended compaction
+                    uint32_t nmask = 0u;
+                    if (alive) nmask = cull_mask(lg, a.G, o, d);
+                    const uint32_t nb = nmask & boxbits;
+                    const bool complex = alive && ((nmask & sphbits) != 0u || (nb & (nb - 1u)) != 0u);
+                    const u64 b0 = __ballot(alive && !complex), b1 = __ballot(complex);
+                    if (alive) {
+                        const u64 bb = complex ? b1 : b0;
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bb, 0u));
+                        const uint32_t oi = complex ? base + S - 1u - (run1 + rank) : base + run0 + rank;
+                        float *out = a.out;
+                        out[oi] = o.x; (out + cap)[oi] = o.y; (out + 2 * cap)[oi] = o.z;
+                        (out + 3 * cap)[oi] = d.x; (out + 4 * cap)[oi] = d.y; (out + 5 * cap)[oi] = d.z;
+                        (out + 6 * cap)[oi] = thr.x; (out + 7 * cap)[oi] = thr.y; (out + 8 * cap)[oi] = thr.z;
+                        reinterpret_cast<uint32_t *>(out + 9 * cap)[oi] = pv;
+                        reinterpret_cast<uint32_t *>(out + 10 * cap)[oi] = nmask;
+                    }
+                    run0 += (uint32_t)__popcll(b0);
+                    run1 += (uint32_t)__popcll(b1);
+                }
+            }
+        }
+        if (!LAST && lane == 0) { a.cnt_out[seg] = run0; a.cnt_out[a.bin1_offset + seg] = run1; }
+        survivors += run0 + run1;
     }
 
     for (int sft = 32; sft > 0; sft >>= 1) emitted += __shfl_down(emitted, sft);
@@ -1170,6 +1340,7 @@ struct pt_context {
     bool seg_mode = true;            // wave-autonomous segmented compaction (cfg.compaction == 0)
     bool cull = true;                // AABB candidate culling in front of the exact tests (cfg.culling == 0)
     bool defer = false;              // sparse-work queue kernel (cfg.ordering == 1; needs LDS geometry, G <= 32)
+    bool binned = false;             // two-ended binned compaction (cfg.ordering == 2; LDS geometry, G <= 32)
     bool use_bvh = false;            // candidate-list kernel (cfg.bvh 1 = BVH walk, 2 = uniform scan; <= 256 primitives)
     BvhNode *d_nodes = nullptr; BoundRec *d_bounds = nullptr; unsigned char *d_order = nullptr;
     int nnodes = 0;
@@ -1385,6 +1556,14 @@ int launch_seg_lc(pt_context *c, const SegArgs &a, bool last, bool gen) {
 }
 
 template <bool LAST, bool GEN>
+int launch_bin_t(pt_context *c, const SegArgs &a) {
+    hipLaunchKernelGGL((k_bounce_bin<LAST, GEN>), dim3(c->grid_bounce), dim3(kBlock), c->lds_bytes, c->stream, a,
+                       (const GeomRec *)c->d_geoms, (const MatRec *)c->d_mats);
+    HIPCHK(hipGetLastError());
+    return PT_OK;
+}
+
+template <bool LAST, bool GEN>
 int launch_defer_t(pt_context *c, const SegArgs &a) {
     hipLaunchKernelGGL((k_bounce_defer<LAST, GEN>), dim3(c->grid_bounce), dim3(kBlock), c->lds_bytes, c->stream, a,
                        (const GeomRec *)c->d_geoms, (const MatRec *)c->d_mats);
@@ -1397,6 +1576,10 @@ int launch_seg(pt_context *c, const SegArgs &a, bool last, bool gen) {
     if (c->use_bvh) {
         if (gen) return last ? launch_bvh_t<true, true>(c, a) : launch_bvh_t<false, true>(c, a);
         return last ? launch_bvh_t<true, false>(c, a) : launch_bvh_t<false, false>(c, a);
+    }
+    if (c->binned) {
+        if (gen) return last ? launch_bin_t<true, true>(c, a) : launch_bin_t<false, true>(c, a);
+        return last ? launch_bin_t<true, false>(c, a) : launch_bin_t<false, false>(c, a);
     }
     if (c->defer) {
         if (gen) return last ? launch_defer_t<true, true>(c, a) : launch_defer_t<false, true>(c, a);
@@ -1413,10 +1596,11 @@ int launch_seg(pt_context *c, const SegArgs &a, bool last, bool gen) {
 uint32_t seg_slots_for(const pt_context *c, uint32_t n_rays) {
     if (c->cfg.chunk_rays > 0) return c->seg_slots;
     // the sparse-work queue drains once per segment (one partly filled group): longer segments there
-    const uint32_t slots = (uint32_t)c->grid_bounce * kWaves * (c->defer ? 2u : 4u);
+    const bool longseg = c->defer || c->binned;
+    const uint32_t slots = (uint32_t)c->grid_bounce * kWaves * (longseg ? 2u : 4u);
     uint32_t S = (((n_rays + slots - 1) / slots) + 63u) & ~63u;
     if (S < 192u) S = 192u;
-    if (S > (c->defer ? 2048u : 1024u)) S = c->defer ? 2048u : 1024u;
+    if (S > (longseg ? 2048u : 1024u)) S = longseg ? 2048u : 1024u;
     return S;
 }
 
@@ -1426,7 +1610,7 @@ void plan_levels(const pt_context *c, uint32_t n_rays, uint32_t *slots, uint32_t
     const uint32_t floor_segs = (uint32_t)(c->cfg.merge_floor > 0 ? c->cfg.merge_floor : 0);
     for (int b = 0; b < c->cfg.max_depth; ++b) {
         const uint32_t half = (nseg[b] + 1u) / 2u;
-        const bool merge = c->cfg.merge_floor > 0 && half >= floor_segs && slots[b] * 2u <= 65536u;
+        const bool merge = c->cfg.merge_floor > 0 && !c->binned && half >= floor_segs && slots[b] * 2u <= 65536u;
         slots[b + 1] = merge ? slots[b] * 2u : slots[b];
         nseg[b + 1] = merge ? half : nseg[b];
     }
@@ -1464,6 +1648,7 @@ int enqueue_iterations(pt_context *c, uint32_t iteration, uint32_t batch, int st
         a.merge = c->lvl_slots[b + 1] != c->lvl_slots[b] ? 1u : 0u;
         a.bounce = b; a.iteration = iteration; a.n_own = c->n_own; a.cam = c->cam; a.bank = c->bank;
         a.n_rays = n_rays; a.batch = batch; a.planes = c->d_planes; a.plane_stride = (size_t)c->W * c->H * 3;
+        a.bin1_offset = c->nseg + 2u;
         const bool last = (stop_after < 0) && (b == D - 1);
         int rc = launch_seg(c, a, last, b == 0);
         if (rc) return rc;
@@ -1589,7 +1774,8 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     c->cull = (c->cfg.culling == 0) && c->seg_mode;
     c->defer = c->cull && c->cfg.ordering == 1 && c->cfg.geometry_path == 0 && G <= 32 && c->cfg.mode == 0;
     c->use_bvh = c->cull && c->cfg.mode == 0 && G <= 256 && (c->cfg.bvh == 1 || c->cfg.bvh == 2);   // opt-in: measured slower than block-wise culling
-    if (c->use_bvh) c->defer = false;
+    c->binned = c->cull && c->cfg.ordering == 2 && c->cfg.geometry_path == 0 && G <= 32 && c->cfg.mode == 0;
+    if (c->use_bvh) { c->defer = false; c->binned = false; }
     c->geom_lds = (c->cfg.geometry_path == 0);
 
     if (c->use_bvh) {
@@ -1649,7 +1835,8 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     int per_cu = c->cfg.blocks_per_cu;
     if (per_cu <= 0) {
         int occ = 0;
-        const void *fn = c->use_bvh ? reinterpret_cast<const void *>(&k_bounce_bvh<false, false>)
+        const void *fn = c->binned ? reinterpret_cast<const void *>(&k_bounce_bin<false, false>)
+                       : c->use_bvh ? reinterpret_cast<const void *>(&k_bounce_bvh<false, false>)
                        : c->defer ? reinterpret_cast<const void *>(&k_bounce_defer<false, false>) : fns[(c->seg_mode ? 4 : 0) + (c->geom_lds ? 0 : 1)];
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, kBlock, c->lds_bytes) != hipSuccess || occ < 1) occ = 2;
         per_cu = occ;
@@ -1692,8 +1879,8 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         c->grid_bounce = grid;
         plan_levels(c, max_rays, c->lvl_slots, c->lvl_nseg);
         for (int i = 0; i < 2; ++i) {
-            HIPCHK(hipMalloc(&c->d_segcnt[i], (size_t)(c->nseg + 2u) * sizeof(uint32_t)));
-            HIPCHK(hipMemset(c->d_segcnt[i], 0, (size_t)(c->nseg + 2u) * sizeof(uint32_t)));
+            HIPCHK(hipMalloc(&c->d_segcnt[i], (size_t)(c->nseg + 2u) * 2 * sizeof(uint32_t)));     // [bin 0 | bin 1]
+            HIPCHK(hipMemset(c->d_segcnt[i], 0, (size_t)(c->nseg + 2u) * 2 * sizeof(uint32_t)));
         }
         c->status_words = 0;
     } else {
@@ -1708,7 +1895,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     if (grid < 1) grid = 1;
     c->grid_bounce = grid;
 
-    for (int i = 0; i < 2; ++i) HIPCHK(hipMalloc(&c->pool[i], (size_t)c->cap * kFields * sizeof(float)));
+    for (int i = 0; i < 2; ++i) HIPCHK(hipMalloc(&c->pool[i], (size_t)c->cap * kPoolFields * sizeof(float)));
     HIPCHK(hipMalloc(&c->image_own, (size_t)W * H * 3 * sizeof(float)));
     HIPCHK(hipMemset(c->image_own, 0, (size_t)W * H * 3 * sizeof(float)));
     if (!c->image) c->image = c->image_own;
@@ -1920,8 +2107,11 @@ int pt_debug_trace_pool(pt_context *c, int iteration, int bounces, int *count, f
         std::vector<uint32_t> cnt(nseg);
         HIPCHK(hipMemcpy(cnt.data(), c->d_segcnt[bounces & 1], (size_t)nseg * 4, hipMemcpyDeviceToHost));
         std::vector<float> field(c->cap);
+        std::vector<uint32_t> cnt1(nseg, 0u);
+        if (c->binned && bounces > 0)
+            HIPCHK(hipMemcpy(cnt1.data(), c->d_segcnt[bounces & 1] + c->nseg + 2u, (size_t)nseg * 4, hipMemcpyDeviceToHost));
         uint64_t total = 0;
-        for (uint32_t sgi = 0; sgi < nseg; ++sgi) total += cnt[sgi];
+        for (uint32_t sgi = 0; sgi < nseg; ++sgi) total += cnt[sgi] + cnt1[sgi];
         if (total != n) { pth::set_error("segment counts (%llu) disagree with the live counter (%u)", (unsigned long long)total, n); return PT_ERR_HIP; }
         for (int f = 0; f < 10; ++f) {
             float *out = f < 9 ? dst[f] : reinterpret_cast<float *>(pixel);
@@ -1931,6 +2121,8 @@ int pt_debug_trace_pool(pt_context *c, int iteration, int bounces, int *count, f
             for (uint32_t sgi = 0; sgi < nseg; ++sgi) {
                 memcpy(out + w, field.data() + (size_t)sgi * slots, (size_t)cnt[sgi] * 4);
                 w += cnt[sgi];
+                if (c->binned && bounces > 0)                         // back run of the two-ended segment
+                    for (uint32_t q = 0; q < cnt1[sgi]; ++q) out[w++] = field[(size_t)sgi * slots + slots - 1u - q];
             }
         }
     }
