@@ -5,6 +5,7 @@ and travels to the GPU box as a binary (the reference sources do not)."""
 import hashlib
 import json
 import os
+import re
 import subprocess
 
 import numpy as np
@@ -37,9 +38,17 @@ def test_error_convention_without_gpu(tmp_path):
     assert r.stderr.startswith("Cuda error: ") and r.stderr.rstrip().endswith(".")   # raytraceKernel.cu:23
 
 
+def _retarget(text, w, h, iters):
+    text, n = re.subn(r"^RES\s+\d+\s+\d+$", "RES %d %d" % (w, h), text, flags=re.M)
+    assert n == 1
+    text, n = re.subn(r"^ITERATIONS\s+\d+$", "ITERATIONS %d" % iters, text, flags=re.M)
+    assert n == 1
+    return text
+
+
 def _small_scene(tmp_path, w, h, iters):
     text = open(os.path.join(ROOT, "scenes", "cornell_mirror.txt")).read()
-    text = text.replace("RES         1920 1080", "RES         %d %d" % (w, h)).replace("ITERATIONS  1000", "ITERATIONS  %d" % iters)
+    text = _retarget(text, w, h, iters)
     p = tmp_path / "small.txt"
     p.write_text(text)
     return str(p)
@@ -126,11 +135,14 @@ def test_frame_argument_selects_the_frame(tmp_path):
     """`frame=1` (src/main.cpp:39-42): the second frame of the scene file is flattened and rendered,
     the output is named X.1.bmp (src/main.cpp:148-154)."""
     text = open(os.path.join(ROOT, "scenes", "cornell_mirror.txt")).read()
-    text = text.replace("RES         1920 1080", "RES         48 32").replace("ITERATIONS  1000", "ITERATIONS  2")
-    # move the camera in frame 1 only
-    head, sep, tail = text.partition("frame 1\nEYE         0 4.5 12")
+    text = _retarget(text, 48, 32, 2)
+    # move the camera in frame 1 only (the CAMERA block's second frame)
+    cam_at = text.index("CAMERA")
+    head, sep, tail = text[cam_at:].partition("frame 1\n")
     assert sep
-    text = head + "frame 1\nEYE         1 4.5 11" + tail
+    tail, n = re.subn(r"^EYE 0 4\.5 12$", "EYE 1 4.5 11", tail, count=1, flags=re.M)
+    assert n == 1
+    text = text[:cam_at] + head + sep + tail
     p = tmp_path / "two_frames.txt"
     p.write_text(text)
     outs = []

@@ -64,20 +64,18 @@ def write_scene(path, materials, objects, res, iterations, outfile, frames=2, ca
     L = []
     for i, m in enumerate(materials):
         rgb, specex, specrgb, refl, refr, ior, scatter, absc, rsct, emit = m
-        L += ["MATERIAL %d" % i, "RGB         " + triple(rgb), "SPECEX      " + num(specex),
-              "SPECRGB     " + triple(specrgb), "REFL        " + num(refl), "REFR        " + num(refr),
-              "REFRIOR     " + num(ior), "SCATTER     " + num(scatter), "ABSCOEFF    " + triple(absc),
-              "RSCTCOEFF   " + num(rsct), "EMITTANCE   " + num(emit), ""]
-    L += ["CAMERA", "RES         %d %d" % res, "FOVY        " + num(camera["fovy"]),
-          "ITERATIONS  %d" % iterations, "FILE        " + outfile]
+        # the parser accepts the ten property lines in any order (src/scene.cpp:230-258)
+        L += ["MATERIAL %d" % i, "EMITTANCE " + num(emit), "RGB " + triple(rgb), "REFL " + num(refl),
+              "REFR " + num(refr), "REFRIOR " + num(ior), "SPECRGB " + triple(specrgb), "SPECEX " + num(specex),
+              "SCATTER " + num(scatter), "ABSCOEFF " + triple(absc), "RSCTCOEFF " + num(rsct), ""]
+    L += ["CAMERA", "FILE " + outfile, "ITERATIONS %d" % iterations, "RES %d %d" % res, "FOVY " + num(camera["fovy"])]
     for f in range(frames):
-        L += ["frame %d" % f, "EYE         " + triple(camera["eye"]), "VIEW        " + triple(camera["view"]),
-              "UP          " + triple(camera["up"])]
+        L += ["frame %d" % f, "UP " + triple(camera["up"]), "VIEW " + triple(camera["view"]), "EYE " + triple(camera["eye"])]
     L += [""]
     for i, (typ, mat, t, r, s) in enumerate(objects):
         L += ["OBJECT %d" % i, typ, "material %d" % mat]
         for f in range(frames):
-            L += ["frame %d" % f, "TRANS       " + triple(t), "ROTAT       " + triple(r), "SCALE       " + triple(s)]
+            L += ["frame %d" % f, "SCALE " + triple(s), "ROTAT " + triple(r), "TRANS " + triple(t)]
         L += [""]
     with open(path, "w", newline="\n") as fh:
         fh.write("\n".join(L))
