@@ -194,6 +194,25 @@ def load_golden_scene(name, frame=0):
     return Scene(geoms, mats, cam, c["iterations"], c["imageName"])
 
 
+def scene_from_pods(geoms, materials, camera):
+    """Oracle scene from the product's pt_geom / pt_material / pt_camera PODs (SceneFile.flatten)."""
+    sc = Scene([], [], Camera())
+    for g in geoms:
+        og = Geom()
+        og.type, og.materialid = g.type, g.materialid
+        for k in range(12):
+            og.transform[k] = g.transform[k]
+            og.inverseTransform[k] = g.inverseTransform[k]
+        og.transform[15] = og.inverseTransform[15] = 1.0
+        sc.geoms.append(og)
+    for m in materials:
+        om = Material()
+        C.memmove(C.byref(om), C.byref(m), 64)
+        sc.materials.append(om)
+    C.memmove(C.byref(sc.camera), C.byref(camera), 52)
+    return sc
+
+
 def default_config(depth=8, **kw):
     cfg = Config(max_depth=depth, camera_mode=0, antialias=0, aperture=0.0, focal_distance=0.0,
                  row_offset=0, row_stride=1)
