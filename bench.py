@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--resolution", default="", help="WxH override of the scene RES line (experiments only)")
     ap.add_argument("--culling", type=int, default=0, help="0 = AABB candidate culling (default), 1 = brute force")
     ap.add_argument("--compaction", type=int, default=0, help="0 = segmented (default), 1 = look-back scan")
+    ap.add_argument("--direct-light", type=int, default=0, help="1 = next-event estimation (one shadow ray per diffuse hit); not the headline configuration")
     args = ap.parse_args()
 
     import torch
@@ -169,7 +170,7 @@ def main():
     tracer = pkg.PathTracer(pkg.default_config(device=device, max_depth=depth, row_offset=rank, row_stride=world,
                                                geometry_path=args.geometry_path, chunk_rays=args.chunk_rays,
                                                blocks_per_cu=args.blocks_per_cu, culling=args.culling, merge_floor=args.merge_floor, batch=args.batch, ordering=args.ordering, bvh=args.bvh,
-                                               compaction=args.compaction))
+                                               compaction=args.compaction, direct_light=args.direct_light))
     tracer.upload(geoms, mats, cam)
     accum = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda:%d" % device)
     tracer.bind_device_image(accum)
@@ -263,6 +264,7 @@ def main():
                        "rays_per_step": W * H, "sharding": "rows interleaved over %d GPU(s), 1 RCCL reduce per frame" % world,
                        "live_ray_bounces_per_step": round(sum(live[:depth]) / max(1, int(stats.iterations))),
                        "compaction": ("segmented, wave-autonomous; " + {0: "stable order (ordering=0)", 1: "sparse-work queue (ordering=1)", 2: "binned two-ended (ordering=2)"}[args.ordering]) if args.compaction == 0 else "global look-back scan",
+                       "direct_light": bool(args.direct_light),
                        "ms_per_step_with_kernel_events": round(elapsed_events / args.steps * 1e3, 4) if elapsed_events else None},
             "roofline": roof,
         }

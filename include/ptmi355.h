@@ -114,7 +114,12 @@ typedef struct {
                                 DESIGN.md): 1 = per-lane BVH walk (LDS nodes, per-lane stack and candidate
                                 lists), 2 = wave-uniform scan of the bounds into per-lane candidate lists;
                                 0 = off */
-    int   reserved[1];
+    int   direct_light;      /* 1 = next-event estimation: at every diffuse hit one shadow
+                                ray to a point drawn by getRandomPointOnCube / getRandomPointOnSphere
+                                (src/intersections.h:220-286) on a random emitter; emitter hits then add
+                                radiance only for camera rays and after specular events.  Same expectation
+                                as mode 0 without it, far less noise for small lights.  Needs compaction=0,
+                                culling=0, geometry_path=0 (LDS tables); ordering/bvh are ignored. */
 } pt_config;
 
 typedef struct pt_context pt_context;

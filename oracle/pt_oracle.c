@@ -348,6 +348,40 @@ void orc_random_point_on_sphere(const orc_geom *sphere, float randomSeed, float 
     vstore(out, mulmv(sphere->transform, V(x, y, z), 1.0f));
 }
 
+/* Light sample for next-event estimation (build-defined): the reference's own
+ * samplers above (src/intersections.h:220-286, written for exactly this use, no call sites there) and
+ * the reciprocal of the density they induce per unit WORLD area.
+ *   cube:   faces are picked by area and points are uniform on a face -> density 1/totalarea;
+ *   sphere: (x,y) uniform on the unit square, z = +-sqrt(r^2-x^2-y^2) with probability 1/2 each ->
+ *           density |z| per unit area of the unit-diameter sphere (dA = dx dy / |z/r|, r = 1/2), divided
+ *           by the area scale (2*radii.x)^2 of the (uniformly scaled) transform; samples outside the
+ *           disk (NaN) are unusable and contribute nothing, which the density accounts for. */
+int orc_sample_light(const orc_geom *g, float randomSeed, float Q[3], float *inv_pdf_area) {
+    float radii[3];
+    orc_get_radiuses(g, radii);
+    if (g->type == 1) {
+        float side1 = radii[0] * radii[1] * 4.0f;
+        float side2 = radii[2] * radii[1] * 4.0f;
+        float side3 = radii[0] * radii[2] * 4.0f;
+        float totalarea = 2.0f * (side1 + side2 + side3);
+        orc_random_point_on_cube(g, randomSeed, Q);
+        *inv_pdf_area = totalarea;
+        return totalarea > 0.0f;
+    }
+    if (g->type == 0) {
+        const float radius = .5f;
+        uint32_t st = orc_lcg_seed(orc_hash((uint32_t)randomSeed));
+        st = orc_lcg_next(st); float x = dist_ab(st, -0.5f, 0.5f);
+        st = orc_lcg_next(st); float y = dist_ab(st, -0.5f, 0.5f);
+        float z = sqrtf(radius * radius - x * x - y * y);      /* |z| of the point the sampler returns */
+        orc_random_point_on_sphere(g, randomSeed, Q);
+        float s = 2.0f * radii[0];
+        *inv_pdf_area = (s * s) / z;
+        return z > 0.0f;                                       /* false for NaN and for the rim */
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------ scatter ------ */
 
 /* src/interactions.h:62-87 */
@@ -662,7 +696,64 @@ int orc_raycast_flat(const orc_geom *geoms, int ngeoms, const orc_material *mats
 typedef struct {
     float o[3], d[3], thr[3];
     int alive;
+    int count_emission;     /* direct_light: the next emitter hit adds its radiance (camera ray / after a
+                               specular event); after a diffuse event the shadow ray already did */
 } path_state;
+
+typedef struct {
+    int n;
+    int *ids;               /* primitives whose material emits, in index order */
+} light_list;
+
+static light_list collect_lights(const orc_geom *geoms, int ngeoms, const orc_material *mats) {
+    light_list l;
+    l.n = 0;
+    l.ids = (int *)malloc(sizeof(int) * (size_t)(ngeoms > 0 ? ngeoms : 1));
+    for (int i = 0; i < ngeoms; i++)
+        if (mats[geoms[i].materialid].emittance > 0.0f) l.ids[l.n++] = i;
+    return l;
+}
+
+/* Next-event estimation at a diffuse hit.  `st` is the bounce's RNG stream after
+ * the three scatter draws; ps holds the scattered ray (origin = biased hit point, thr already multiplied
+ * by the albedo); N is the geometric normal of the hit, d_in the incoming direction. */
+static void direct_light(const orc_geom *geoms, int ngeoms, const orc_material *mats, const light_list *lights,
+                         uint32_t st, const float Nn[3], const float d_in[3], const path_state *ps, float L[3]) {
+    if (lights->n <= 0) return;
+    st = orc_lcg_next(st); float u_l = orc_u01(st);
+    st = orc_lcg_next(st); float seedf = (float)(st & 0xFFFFFFu);
+    int li = (int)(u_l * (float)lights->n);
+    if (li > lights->n - 1) li = lights->n - 1;
+    int lid = lights->ids[li];
+    float Q[3], invpdf;
+    if (!orc_sample_light(&geoms[lid], seedf, Q, &invpdf)) return;
+    v3 o = vload(ps->o);
+    v3 wv = vsub(vload(Q), o);
+    float dist2 = vdot(wv, wv);
+    if (!(dist2 > 0.0f)) return;
+    float dist = sqrtf(dist2);
+    v3 w = vscale(wv, 1.0f / dist);
+    v3 N = vload(Nn);
+    v3 n = vscale(N, 1.0f / sqrtf(vdot(N, N)));
+    v3 nf = (vdot(n, vload(d_in)) > 0.0f) ? vneg(n) : n;
+    float cos_s = vdot(nf, w);
+    if (!(cos_s > 0.0f)) return;
+    float wa[3], t, Ph[3], Nh[3];
+    vstore(wa, w);
+    int hit = orc_nearest_hit(geoms, ngeoms, mats, ps->o, wa, &t, Ph, Nh);
+    if (hit != lid) return;
+    float tol = 1e-3f * (dist > 1.0f ? dist : 1.0f);
+    if (!(t + tol >= dist)) return;                      /* a nearer face of the same emitter hides Q */
+    v3 NH = vload(Nh);
+    float nl2 = vdot(NH, NH);
+    if (!(nl2 > 0.0f)) return;
+    float cos_l = fabsf(vdot(NH, w)) / sqrtf(nl2);
+    float geomf = (((cos_s * cos_l) * invpdf) / (ORC_PI * dist2)) * (float)lights->n;
+    const orc_material *lm = &mats[geoms[lid].materialid];
+    v3 Le = vscale(vload(lm->color), lm->emittance);
+    v3 C = vscale(vmul(vload(ps->thr), Le), geomf);
+    L[0] = L[0] + C.x; L[1] = L[1] + C.y; L[2] = L[2] + C.z;
+}
 
 static void path_generate(const orc_camera_basis *cb, const orc_config *cfg, int W, uint32_t pixel,
                           uint32_t iteration, path_state *ps) {
@@ -678,11 +769,12 @@ static void path_generate(const orc_camera_basis *cb, const orc_config *cfg, int
     orc_camera_ray(cb, cfg, x, y, jx, jy, lu, lv, ps->o, ps->d);
     ps->thr[0] = ps->thr[1] = ps->thr[2] = 1.0f;
     ps->alive = 1;
+    ps->count_emission = 1;
 }
 
 /* one bounce of one path; returns 1 while the path stays alive; adds radiance into L */
-static int path_bounce(const orc_geom *geoms, int ngeoms, const orc_material *mats, uint32_t pixel,
-                       uint32_t iteration, int bounce, int last, path_state *ps, float L[3]) {
+static int path_bounce(const orc_geom *geoms, int ngeoms, const orc_material *mats, const light_list *lights,
+                       uint32_t pixel, uint32_t iteration, int bounce, int last, path_state *ps, float L[3]) {
     float t, P[3], N[3];
     int hit = orc_nearest_hit(geoms, ngeoms, mats, ps->o, ps->d, &t, P, N);
     if (hit < 0) return 0;
@@ -692,7 +784,17 @@ static int path_bounce(const orc_geom *geoms, int ngeoms, const orc_material *ma
     st = orc_lcg_next(st); float u_sel = orc_u01(st);
     st = orc_lcg_next(st); float xi1 = orc_u01(st);
     st = orc_lcg_next(st); float xi2 = orc_u01(st);
-    int code = orc_scatter(m, P, N, u_sel, xi1, xi2, ps->o, ps->d, ps->thr, L);
+    float d_in[3] = {ps->d[0], ps->d[1], ps->d[2]};
+    float Le[3] = {0, 0, 0};
+    int code = orc_scatter(m, P, N, u_sel, xi1, xi2, ps->o, ps->d, ps->thr, Le);
+    if (code == 3 && (!lights || ps->count_emission)) {
+        /* contributions of one path are summed in bounce order, starting from zero */
+        L[0] = L[0] + Le[0]; L[1] = L[1] + Le[1]; L[2] = L[2] + Le[2];
+    }
+    if (lights) {
+        if (code == 0) direct_light(geoms, ngeoms, mats, lights, st, N, d_in, ps, L);
+        ps->count_emission = (code == 1 || code == 2);
+    }
     return code <= 2;
 }
 
@@ -710,6 +812,8 @@ int orc_render(const orc_geom *geoms, int ngeoms, const orc_material *mats, int 
     nthreads = clamp_threads(nthreads);
     uint64_t *tl = (uint64_t *)calloc((size_t)nthreads * 65, sizeof(uint64_t));
     if (!tl) return -2;
+    light_list ll = collect_lights(geoms, ngeoms, mats);
+    const light_list *lights = cfg->direct_light ? &ll : NULL;
 #pragma omp parallel for schedule(dynamic, 2) num_threads(nthreads)
     for (int y = 0; y < H; y++) {
         if (y % stride != offset) continue;
@@ -727,7 +831,7 @@ int orc_render(const orc_geom *geoms, int ngeoms, const orc_material *mats, int 
                 mine[0]++;
                 int b;
                 for (b = 0; b < D; b++) {
-                    if (!path_bounce(geoms, ngeoms, mats, pixel, (uint32_t)it, b, b == D - 1, &ps, L)) break;
+                    if (!path_bounce(geoms, ngeoms, mats, lights, pixel, (uint32_t)it, b, b == D - 1, &ps, L)) break;
                     mine[b + 1]++;
                 }
                 /* one add per pixel per iteration, in iteration order (main.cpp:146 divides later) */
@@ -745,6 +849,7 @@ int orc_render(const orc_geom *geoms, int ngeoms, const orc_material *mats, int 
         }
     }
     free(tl);
+    free(ll.ids);
     return 0;
 }
 
@@ -758,6 +863,8 @@ int orc_trace_pool(const orc_geom *geoms, int ngeoms, const orc_material *mats, 
     int W = (int)cam->resolution[0], H = (int)cam->resolution[1];
     int stride = cfg->row_stride > 0 ? cfg->row_stride : 1;
     int n = 0;
+    light_list ll = collect_lights(geoms, ngeoms, mats);
+    const light_list *lights = cfg->direct_light ? &ll : NULL;
     for (int y = 0; y < H; y++) {
         if (y % stride != cfg->row_offset) continue;
         for (int x = 0; x < W; x++) {
@@ -767,7 +874,7 @@ int orc_trace_pool(const orc_geom *geoms, int ngeoms, const orc_material *mats, 
             path_generate(&cb, cfg, W, p, (uint32_t)iteration, &ps);
             int alive = 1;
             for (int b = 0; b < bounces && alive; b++)
-                alive = path_bounce(geoms, ngeoms, mats, p, (uint32_t)iteration, b,
+                alive = path_bounce(geoms, ngeoms, mats, lights, p, (uint32_t)iteration, b,
                                     b == cfg->max_depth - 1, &ps, L);
             if (!alive) continue;
             if (ox) ox[n] = ps.o[0];
@@ -779,9 +886,11 @@ int orc_trace_pool(const orc_geom *geoms, int ngeoms, const orc_material *mats, 
             if (tr) tr[n] = ps.thr[0];
             if (tg) tg[n] = ps.thr[1];
             if (tb) tb[n] = ps.thr[2];
-            if (pixel) pixel[n] = p;
+            /* direct_light: bit 31 carries the path's count_emission flag, as in the device pool */
+            if (pixel) pixel[n] = p | ((lights && ps.count_emission) ? 0x80000000u : 0u);
             n++;
         }
     }
+    free(ll.ids);
     return n;
 }

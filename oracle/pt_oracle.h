@@ -100,6 +100,9 @@ typedef struct {
     float focal_distance;   /* distance of the focal plane along `view`                      */
     int   row_offset;       /* multi-GPU row interleave: this shard owns rows y with        */
     int   row_stride;       /*   y % row_stride == row_offset   (1-GPU: 0,1)                 */
+    int   direct_light;     /* 1 = next-event estimation at diffuse hits: one shadow
+                               ray to a point from getRandomPointOnCube/Sphere on a random emitter;
+                               emitter hits then count only for camera rays and after specular events */
 } orc_config;
 
 /* precomputed per-frame camera basis (host side of raycastFromCameraKernel) */
@@ -134,6 +137,9 @@ int   orc_nearest_hit(const orc_geom *geoms, int ngeoms, const orc_material *mat
 void  orc_get_radiuses(const orc_geom *g, float out[3]);
 void  orc_random_point_on_cube(const orc_geom *cube, float randomSeed, float out[3]);
 void  orc_random_point_on_sphere(const orc_geom *sphere, float randomSeed, float out[3]);
+/* point on emitter g from the reference's samplers plus the reciprocal of its density per unit
+ * world area; returns 0 for an unusable sample (sphere: x^2+y^2 > r^2) */
+int   orc_sample_light(const orc_geom *g, float randomSeed, float Q[3], float *inv_pdf_area);
 void  orc_hemisphere(const float n[3], float xi1, float xi2, float out[3]);
 void  orc_reflection_direction(const float n[3], const float i[3], float out[3]);
 int   orc_transmission_direction(const float n[3], const float i[3], float ior_i, float ior_t,

@@ -238,6 +238,35 @@ __device__ __forceinline__ f3 random_point_on_sphere(const float *xf, float rand
     return mul_point(xf, mk(x, y, z));
 }
 
+// Light sample for next-event estimation: the reference's samplers above plus
+// the reciprocal of the density they induce per unit world area (cube: 1/totalarea; sphere: |z|
+// on the unit-diameter sphere over the area scale (2*radii.x)^2).  false = unusable sample.
+__device__ __forceinline__ bool sample_light(const float *xf, int type, float randomSeed, f3 &Q, float &inv_pdf_area) {
+    const f3 radii = get_radiuses(xf);
+    bool ok = false;
+    Q = mk(0.0f, 0.0f, 0.0f);
+    inv_pdf_area = 0.0f;
+    if (type == 1) {
+        const float side1 = radii.x * radii.y * 4.0f;
+        const float side2 = radii.z * radii.y * 4.0f;
+        const float side3 = radii.x * radii.z * 4.0f;
+        const float totalarea = 2.0f * (side1 + side2 + side3);
+        Q = random_point_on_cube(xf, randomSeed);
+        inv_pdf_area = totalarea;
+        ok = totalarea > 0.0f;
+    } else if (type == 0) {
+        uint32_t st = lcg_seed(hash((uint32_t)randomSeed));
+        st = lcg_next(st); const float x = dist_ab(st, -0.5f, 0.5f);
+        st = lcg_next(st); const float y = dist_ab(st, -0.5f, 0.5f);
+        const float z = __builtin_sqrtf(0.5f * 0.5f - x * x - y * y);
+        Q = random_point_on_sphere(xf, randomSeed);
+        const float s = 2.0f * radii.x;
+        inv_pdf_area = (s * s) / z;
+        ok = z > 0.0f;
+    }
+    return ok;
+}
+
 // ---------------------------------------------------------------- scatter --------------
 // calculateRandomDirectionInHemisphere (src/interactions.h:62-87)
 __device__ __forceinline__ f3 hemisphere(f3 normal, float xi1, float xi2) {

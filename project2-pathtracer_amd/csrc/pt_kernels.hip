@@ -334,6 +334,71 @@ __device__ __forceinline__ bool bounce_ray(const GeomRec *lg, const GeomRec *__r
     return shade_hit<LAST>(lm[mid], P, N, bounce, iteration, image, pixel, o, d, thr, emitted);
 }
 
+// direct_light variant (k_bounce_seg only; LDS tables, culling on).  At a diffuse
+// hit one shadow ray goes to a point on a random emitter (the reference's getRandomPointOnCube/Sphere);
+// an emitter hit adds its radiance only while `flag` (camera ray / last event specular) is set.  All of
+// a path's contributions land in its iteration's accumulator plane in bounce order.
+template <bool LAST>
+__device__ __forceinline__ bool bounce_ray_nee(const GeomRec *lg, const GeomRec *__restrict__ geoms, const MatRec *lm, int G,
+                                               const uint32_t *__restrict__ lights, uint32_t nlights, int bounce,
+                                               uint32_t iteration, float *acc, uint32_t pixel, f3 &o, f3 &d, f3 &thr,
+                                               uint32_t &emitted, uint32_t &flag) {
+    float t;
+    f3 P, N;
+    const int hit = nearest_hit_culled<true>(lg, geoms, G, o, d, t, P, N);
+    if (hit < 0) return false;
+    const MatRec m = lm[lg[hit].mat];
+    if (LAST && !(m.emittance > 0.0f)) return true;
+    uint32_t st = lcg_seed(stream_seed(pixel, iteration, 1u + (uint32_t)bounce));
+    st = lcg_next(st); const float u_sel = u01(st);
+    st = lcg_next(st); const float xi1 = u01(st);
+    st = lcg_next(st); const float xi2 = u01(st);
+    const f3 d_in = d;
+    f3 L = mk(0.0f, 0.0f, 0.0f);
+    const int code = scatter(m, P, N, u_sel, xi1, xi2, o, d, thr, L);
+    float *px = acc + (size_t)pixel * 3;
+    if (code == 3) {
+        if (flag) { px[0] = px[0] + L.x; px[1] = px[1] + L.y; px[2] = px[2] + L.z; }
+        emitted++;
+    }
+    if (!LAST && code == 0 && nlights > 0u) {
+        st = lcg_next(st); const float u_l = u01(st);
+        st = lcg_next(st); const float seedf = (float)(st & 0xFFFFFFu);
+        int li = (int)(u_l * (float)nlights);
+        if (li > (int)nlights - 1) li = (int)nlights - 1;
+        const int lid = (int)lights[li];
+        f3 Q;
+        float invpdf;
+        const bool ok = sample_light(lg[lid].xf, lg[lid].type, seedf, Q, invpdf);
+        const f3 wv = Q - o;
+        const float dist2 = dot(wv, wv);
+        if (ok && dist2 > 0.0f) {
+            const float dist = __builtin_sqrtf(dist2);
+            const f3 w = wv * (1.0f / dist);
+            const f3 n = N * (1.0f / __builtin_sqrtf(dot(N, N)));
+            const f3 nf = (dot(n, d_in) > 0.0f) ? neg(n) : n;
+            const float cos_s = dot(nf, w);
+            if (cos_s > 0.0f) {
+                float th = 0.0f;
+                f3 Ph = mk(0.0f, 0.0f, 0.0f), Nh = mk(0.0f, 0.0f, 0.0f);
+                const int h = nearest_hit_culled<true>(lg, geoms, G, o, w, th, Ph, Nh);
+                const float tol = 1e-3f * (dist > 1.0f ? dist : 1.0f);
+                const float nl2 = dot(Nh, Nh);
+                if (h == lid && (th + tol >= dist) && nl2 > 0.0f) {       // a nearer face of the same emitter hides Q
+                    const float cos_l = fabsf(dot(Nh, w)) / __builtin_sqrtf(nl2);
+                    const float geomf = (((cos_s * cos_l) * invpdf) / (PT_PI * dist2)) * (float)nlights;
+                    const MatRec ml = lm[lg[lid].mat];
+                    const f3 Le = mk(ml.color[0], ml.color[1], ml.color[2]) * ml.emittance;
+                    const f3 C = (thr * Le) * geomf;
+                    px[0] = px[0] + C.x; px[1] = px[1] + C.y; px[2] = px[2] + C.z;
+                }
+            }
+        }
+    }
+    flag = (code == 1 || code == 2) ? 1u : 0u;
+    return code <= 2;
+}
+
 // ------------------------------------------------------------------ bounce -------------
 // decoupled look-back over the chunk granules; one lane.  Returns the exclusive prefix.
 __device__ __forceinline__ uint32_t lookback(u64 *status, uint32_t chunk, uint32_t total, SyncBlock *sync) {
@@ -479,12 +544,15 @@ struct SegArgs {
     size_t plane_stride;             //   (floats); folded into the image in iteration order afterwards
     uint32_t bank;                   // counter bank of this launch group (the host alternates 0/1)
     uint32_t bin1_offset;            // binned ordering: bin-1 counts live at cnt[bin1_offset + seg]
+    const uint32_t *lights;          // direct_light: indices of the emitting primitives, in index order
+    uint32_t nlights;
     CamRec cam;
 };
 
-template <bool GEOM_LDS, bool LAST, bool CULL, bool GEN>
+template <bool GEOM_LDS, bool LAST, bool CULL, bool GEN, bool NEE = false>
 __global__ __launch_bounds__(kBlock, PT_SEG_WAVES) void k_bounce_seg(SegArgs a, const GeomRec *__restrict__ geoms,
                                                        const MatRec *__restrict__ mats) {
+    static_assert(!NEE || (GEOM_LDS && CULL), "direct_light runs on the LDS tables with culling");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *ctrl = reinterpret_cast<uint32_t *>(smem);   // [0] survivors, [1] emitted (block sums)
     if (threadIdx.x < 2) ctrl[threadIdx.x] = 0u;
@@ -531,6 +599,7 @@ __global__ __launch_bounds__(kBlock, PT_SEG_WAVES) void k_bounce_seg(SegArgs a, 
             uint32_t pixel = 0u;
             if (k < n) {
                 uint32_t slot;
+                uint32_t flag = 1u;                       // NEE: count-emission bit (bit 31 of the pixel word)
                 if (GEN) {
                     // k_generate fused: ray id -> (iteration slot, owned pixel via the row interleave) -> camera ray
                     const uint32_t gid = base + (k < na ? k : k - na + S);
@@ -550,12 +619,21 @@ __global__ __launch_bounds__(kBlock, PT_SEG_WAVES) void k_bounce_seg(SegArgs a, 
                     d = mk((in + 3 * cap)[idx], (in + 4 * cap)[idx], (in + 5 * cap)[idx]);
                     thr = mk((in + 6 * cap)[idx], (in + 7 * cap)[idx], (in + 8 * cap)[idx]);
                     const uint32_t pv = reinterpret_cast<const uint32_t *>(in + 9 * cap)[idx];
-                    slot = pv >> 24;
+                    slot = NEE ? (pv >> 24) & 0x7Fu : pv >> 24;
+                    flag = pv >> 31;
                     pixel = pv & 0xFFFFFFu;
                 }
-                float *acc = a.batch > 1u ? a.planes + (size_t)slot * a.plane_stride : a.image;
-                alive = bounce_ray<GEOM_LDS, LAST, CULL>(lg, geoms, lm, a.G, a.bounce, a.iteration + slot, acc, pixel, o, d, thr, emitted);
-                pixel |= slot << 24;
+                if (NEE) {
+                    // every contribution of a path goes to its iteration's plane (folded afterwards)
+                    float *acc = a.planes + (size_t)slot * a.plane_stride;
+                    alive = bounce_ray_nee<LAST>(lg, geoms, lm, a.G, a.lights, a.nlights, a.bounce, a.iteration + slot, acc, pixel,
+                                                 o, d, thr, emitted, flag);
+                    pixel |= (slot << 24) | (flag << 31);
+                } else {
+                    float *acc = a.batch > 1u ? a.planes + (size_t)slot * a.plane_stride : a.image;
+                    alive = bounce_ray<GEOM_LDS, LAST, CULL>(lg, geoms, lm, a.G, a.bounce, a.iteration + slot, acc, pixel, o, d, thr, emitted);
+                    pixel |= slot << 24;
+                }
             }
             const u64 ballot = __ballot(alive);
             if (!LAST && alive) {
@@ -1356,6 +1434,9 @@ struct pt_context {
     uint32_t bank = 0;               // counter bank of the iteration being enqueued (fused segmented path)
     uint32_t batch_max = 1;          // iterations that may share one launch group
     float *d_planes = nullptr;       // batch_max accumulator planes (W*H*3 floats each)
+    bool nee = false;                // cfg.direct_light: shadow rays at diffuse hits (k_bounce_seg<.., NEE>)
+    uint32_t *d_lights = nullptr;    // indices of the emitting primitives
+    uint32_t nlights = 0;
     // profiling
     struct Ev { hipEvent_t a, b; int kind; };
     std::vector<Ev> pending;
@@ -1416,6 +1497,8 @@ void free_scene_buffers(pt_context *c) {
     for (int i = 0; i < 2; ++i) { if (c->d_segcnt[i]) (void)hipFree(c->d_segcnt[i]); c->d_segcnt[i] = nullptr; }
     if (c->d_planes) (void)hipFree(c->d_planes);
     c->d_planes = nullptr;
+    if (c->d_lights) (void)hipFree(c->d_lights);
+    c->d_lights = nullptr;
     if (c->d_nodes) (void)hipFree(c->d_nodes);
     if (c->d_bounds) (void)hipFree(c->d_bounds);
     if (c->d_order) (void)hipFree(c->d_order);
@@ -1556,6 +1639,14 @@ int launch_seg_lc(pt_context *c, const SegArgs &a, bool last, bool gen) {
 }
 
 template <bool LAST, bool GEN>
+int launch_nee_t(pt_context *c, const SegArgs &a) {
+    hipLaunchKernelGGL((k_bounce_seg<true, LAST, true, GEN, true>), dim3(c->grid_bounce), dim3(kBlock), c->lds_bytes, c->stream, a,
+                       (const GeomRec *)c->d_geoms, (const MatRec *)c->d_mats);
+    HIPCHK(hipGetLastError());
+    return PT_OK;
+}
+
+template <bool LAST, bool GEN>
 int launch_bin_t(pt_context *c, const SegArgs &a) {
     hipLaunchKernelGGL((k_bounce_bin<LAST, GEN>), dim3(c->grid_bounce), dim3(kBlock), c->lds_bytes, c->stream, a,
                        (const GeomRec *)c->d_geoms, (const MatRec *)c->d_mats);
@@ -1573,6 +1664,10 @@ int launch_defer_t(pt_context *c, const SegArgs &a) {
 
 int launch_seg(pt_context *c, const SegArgs &a, bool last, bool gen) {
     Scoped s(c, 1);
+    if (c->nee) {
+        if (gen) return last ? launch_nee_t<true, true>(c, a) : launch_nee_t<false, true>(c, a);
+        return last ? launch_nee_t<true, false>(c, a) : launch_nee_t<false, false>(c, a);
+    }
     if (c->use_bvh) {
         if (gen) return last ? launch_bvh_t<true, true>(c, a) : launch_bvh_t<false, true>(c, a);
         return last ? launch_bvh_t<true, false>(c, a) : launch_bvh_t<false, false>(c, a);
@@ -1649,11 +1744,12 @@ int enqueue_iterations(pt_context *c, uint32_t iteration, uint32_t batch, int st
         a.bounce = b; a.iteration = iteration; a.n_own = c->n_own; a.cam = c->cam; a.bank = c->bank;
         a.n_rays = n_rays; a.batch = batch; a.planes = c->d_planes; a.plane_stride = (size_t)c->W * c->H * 3;
         a.bin1_offset = c->nseg + 2u;
+        a.lights = c->d_lights; a.nlights = c->nlights;
         const bool last = (stop_after < 0) && (b == D - 1);
         int rc = launch_seg(c, a, last, b == 0);
         if (rc) return rc;
     }
-    if (c->seg_mode && batch > 1u) {
+    if (c->seg_mode && (batch > 1u || c->nee)) {
         Scoped s(c, 0);
         FoldArgs f;
         f.image = c->image; f.planes = c->d_planes; f.plane_stride = (size_t)c->W * c->H * 3;
@@ -1777,6 +1873,22 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     c->binned = c->cull && c->cfg.ordering == 2 && c->cfg.geometry_path == 0 && G <= 32 && c->cfg.mode == 0;
     if (c->use_bvh) { c->defer = false; c->binned = false; }
     c->geom_lds = (c->cfg.geometry_path == 0);
+    c->nee = c->cfg.direct_light != 0 && c->cfg.mode == 0;
+    if (c->nee) {
+        // one kernel family implements it: segmented compaction, culling, LDS tables, generation order
+        if (!c->seg_mode || !c->cull || !c->geom_lds) {
+            pth::set_error("pt_upload_scene: direct_light needs compaction=0, culling=0, geometry_path=0");
+            return PT_ERR_ARGUMENT;
+        }
+        c->defer = false; c->binned = false; c->use_bvh = false;
+        std::vector<uint32_t> lights;
+        for (int i = 0; i < G; ++i)
+            if (mats[geoms[i].materialid].emittance > 0.0f) lights.push_back((uint32_t)i);
+        c->nlights = (uint32_t)lights.size();
+        if (lights.empty()) lights.push_back(0u);
+        HIPCHK(hipMalloc(&c->d_lights, lights.size() * sizeof(uint32_t)));
+        HIPCHK(hipMemcpy(c->d_lights, lights.data(), lights.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
 
     if (c->use_bvh) {
         BvhBuild bb;
@@ -1810,6 +1922,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     const uint32_t stage_bytes = c->seg_mode ? (c->defer ? kWaves * kQueueCap * kQueueFields * (uint32_t)sizeof(float) : 0u)
                                              : kBlock * c->rpt * kFields * (uint32_t)sizeof(float);
     if (c->geom_lds && tb + stage_bytes > 160u * 1024u) {   // table too large for LDS: scalar-load path
+        if (c->nee) { pth::set_error("pt_upload_scene: direct_light needs the geometry table in LDS (%d primitives do not fit)", G); return PT_ERR_ARGUMENT; }
         c->geom_lds = false;
         tb = tables_bytes(G, M, false);
     }
@@ -1826,7 +1939,11 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         reinterpret_cast<const void *>(c->cull ? &k_bounce_seg<false, false, true, true> : &k_bounce_seg<false, false, false, true>),
         reinterpret_cast<const void *>(c->cull ? &k_bounce_seg<true, true, true, true> : &k_bounce_seg<true, true, false, true>),
         reinterpret_cast<const void *>(c->cull ? &k_bounce_seg<false, true, true, true> : &k_bounce_seg<false, true, false, true>)};
+    const void *nee_fns[4] = {
+        reinterpret_cast<const void *>(&k_bounce_seg<true, false, true, false, true>), reinterpret_cast<const void *>(&k_bounce_seg<true, true, true, false, true>),
+        reinterpret_cast<const void *>(&k_bounce_seg<true, false, true, true, true>), reinterpret_cast<const void *>(&k_bounce_seg<true, true, true, true, true>)};
     if (c->lds_bytes > 64u * 1024u) {
+        for (const void *fn : nee_fns) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         for (const void *fn : fns) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         for (const void *fn : gen_fns) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
@@ -1835,7 +1952,8 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     int per_cu = c->cfg.blocks_per_cu;
     if (per_cu <= 0) {
         int occ = 0;
-        const void *fn = c->binned ? reinterpret_cast<const void *>(&k_bounce_bin<false, false>)
+        const void *fn = c->nee ? nee_fns[0]
+                       : c->binned ? reinterpret_cast<const void *>(&k_bounce_bin<false, false>)
                        : c->use_bvh ? reinterpret_cast<const void *>(&k_bounce_bvh<false, false>)
                        : c->defer ? reinterpret_cast<const void *>(&k_bounce_defer<false, false>) : fns[(c->seg_mode ? 4 : 0) + (c->geom_lds ? 0 : 1)];
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, kBlock, c->lds_bytes) != hipSuccess || occ < 1) occ = 2;
@@ -1869,7 +1987,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         c->nseg = (max_rays + S - 1) / S;                 // S here = the smallest segment size in use
         c->cap = max_rays + 2u * (c->cfg.merge_floor > 0 ? 65536u : 4096u);
         c->max_chunks = c->nseg;
-        if (K > 1u) {
+        if (K > 1u || c->nee) {
             HIPCHK(hipMalloc(&c->d_planes, (size_t)K * W * H * 3 * sizeof(float)));
             HIPCHK(hipMemset(c->d_planes, 0, (size_t)K * W * H * 3 * sizeof(float)));
         }
@@ -2126,6 +2244,10 @@ int pt_debug_trace_pool(pt_context *c, int iteration, int bounces, int *count, f
             }
         }
     }
+    // direct_light: camera rays carry the count-emission flag implicitly (generation is fused into the
+    // first bounce launch and never writes it); show it the way later pools do
+    if (c->nee && bounces == 0 && pixel)
+        for (uint32_t i = 0; i < n; ++i) pixel[i] |= 0x80000000u;
     return check_device_error(c);
 }
 

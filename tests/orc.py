@@ -35,7 +35,7 @@ class Camera(C.Structure):
 class Config(C.Structure):
     _fields_ = [("max_depth", C.c_int), ("camera_mode", C.c_int), ("antialias", C.c_int),
                 ("aperture", C.c_float), ("focal_distance", C.c_float), ("row_offset", C.c_int),
-                ("row_stride", C.c_int)]
+                ("row_stride", C.c_int), ("direct_light", C.c_int)]
 
 
 class CameraBasis(C.Structure):
@@ -80,6 +80,7 @@ def lib():
     L.orc_get_radiuses.restype = None; L.orc_get_radiuses.argtypes = [C.POINTER(Geom), f3]
     L.orc_random_point_on_cube.restype = None; L.orc_random_point_on_cube.argtypes = [C.POINTER(Geom), C.c_float, f3]
     L.orc_random_point_on_sphere.restype = None; L.orc_random_point_on_sphere.argtypes = [C.POINTER(Geom), C.c_float, f3]
+    L.orc_sample_light.restype = C.c_int; L.orc_sample_light.argtypes = [C.POINTER(Geom), C.c_float, f3, f3]
     L.orc_hemisphere.restype = None; L.orc_hemisphere.argtypes = [f3, C.c_float, C.c_float, f3]
     L.orc_reflection_direction.restype = None; L.orc_reflection_direction.argtypes = [f3, f3, f3]
     L.orc_transmission_direction.restype = C.c_int
@@ -215,7 +216,7 @@ def scene_from_pods(geoms, materials, camera):
 
 def default_config(depth=8, **kw):
     cfg = Config(max_depth=depth, camera_mode=0, antialias=0, aperture=0.0, focal_distance=0.0,
-                 row_offset=0, row_stride=1)
+                 row_offset=0, row_stride=1, direct_light=0)
     for k, v in kw.items():
         setattr(cfg, k, v)
     return cfg

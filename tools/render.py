@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Render a scene file on the GPU and save the gamma-corrected picture (visual sanity check).
-usage: tools/render.py <scene.txt> <out.png> [iterations] [depth]"""
+usage: tools/render.py <scene.txt> <out.png> [iterations] [depth] [direct_light 0|1]"""
 import importlib
 import os
 import sys
@@ -17,9 +17,10 @@ def main():
     scene, out = sys.argv[1], sys.argv[2]
     iters = int(sys.argv[3]) if len(sys.argv) > 3 else 500
     depth = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+    direct = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     sf = pkg.SceneFile(scene)
     g, m, cam = sf.flatten(0)
-    tr = pkg.PathTracer(pkg.default_config(max_depth=depth, ordering=1))
+    tr = pkg.PathTracer(pkg.default_config(max_depth=depth, ordering=1, direct_light=direct))
     tr.upload(g, m, cam)
     tr.set_image(None)
     t0 = time.time()
@@ -29,7 +30,7 @@ def main():
     u8 = pkg.image_to_u8(img, iters, np.float32(1.0 / 2.2))
     from PIL import Image
     Image.fromarray(u8).save(out, optimize=True)
-    print("%s: %dx%d, %d iterations, depth %d in %.2f s; mean gamma RGB %s" % (out, tr.W, tr.H, iters, depth, dt, (u8.reshape(-1, 3).mean(0) / 255).round(3)))
+    print("%s: %dx%d, %d iterations, depth %d%s in %.2f s; mean gamma RGB %s" % (out, tr.W, tr.H, iters, depth, ", direct light sampling" if direct else "", dt, (u8.reshape(-1, 3).mean(0) / 255).round(3)))
 
 
 if __name__ == "__main__":
