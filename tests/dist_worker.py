@@ -3,7 +3,8 @@
 The product has no CPU renderer, so the per-rank shard is produced by the oracle (allowed inside
 tests/); what is under test is the multi-GPU DECOMPOSITION that bench.py uses on the GPUs: rows
 interleaved over ranks (row y -> rank y % world), full-frame accumulators with zeros elsewhere, one
-reduce(sum) to rank 0 (bench.reduce_to_root) -- and that the result is bit-identical to a single
+exchange per frame -- the owned rows gathered on rank 0 (bench.gather_rows_to_root, bench.py's
+default) or a reduce(sum) (bench.reduce_to_root) -- and that the result is bit-identical to a single
 rank rendering the whole frame."""
 import os
 import sys
@@ -21,6 +22,7 @@ import bench        # noqa: E402
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     out = sys.argv[1]
+    exchange = sys.argv[2] if len(sys.argv) > 2 else "reduce"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     scene = orc.load_golden_scene("cornell_mirror").with_resolution(96, 54)
     iters, depth = 3, 6
@@ -29,7 +31,10 @@ def main():
     rows = np.arange(scene.H) % world == rank
     assert not part[~rows].any()
     acc = torch.from_numpy(part.reshape(-1).copy())
-    bench.reduce_to_root(acc, 0)
+    if exchange == "gather":
+        bench.gather_rows_to_root(acc, scene.H, scene.W, 0)      # owned rows only (bench.py's default)
+    else:
+        bench.reduce_to_root(acc, 0)
     counts = torch.from_numpy(live.astype(np.int64))
     dist.reduce(counts, dst=0, op=dist.ReduceOp.SUM)
     if rank == 0:

@@ -17,15 +17,15 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_row_sharded_reduce_is_bit_identical(tmp_path, world):
+@pytest.mark.parametrize("world,exchange", [(2, "gather"), (2, "reduce"), (3, "gather"), (3, "reduce"), (4, "gather")])
+def test_row_sharded_exchange_is_bit_identical(tmp_path, world, exchange):
     port = _free_port()
     out = tmp_path / "result.txt"
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OMP_NUM_THREADS="2")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(out)], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(out), exchange], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = []
     for p in procs:
