@@ -99,7 +99,7 @@ typedef struct {
     int   merge_floor;       /* segmented mode, optional: a bounce merges neighbouring segments while the
                                 halved segment count stays >= this (0 = never merge, the default) */
     int   batch;             /* iterations that may share one launch group in pt_render (0 = auto: about
-                                32 M rays per launch, at most 32; 1 = one iteration per launch).  Results
+                                32 M rays per launch, at most 128; 1 = one iteration per launch).  Results
                                 are identical: each in-flight iteration accumulates into its own plane
                                 and the planes are folded into the image in iteration order. */
     int   ordering;          /* 0 = stable: the compacted stream keeps generation order (default)

@@ -161,6 +161,21 @@ def test_image_and_live_counts_match_oracle(pt, scene_name, depth, iters):
     assert not np.isnan(img).any()
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(ordering=1), dict(ordering=2), dict(direct_light=1)])
+def test_long_launch_groups_use_every_slot_bit(pt, kw):
+    """Small frames batch up to 128 iterations into one launch group (slot = bits 24..30 of the pixel
+    word, bit 31 = the direct-light flag): 150 iterations = one full group + a partial one."""
+    sc = orc.load_golden_scene("cornell_mirror").with_resolution(64, 48)
+    tr = make_tracer(sc, depth=4, **kw)
+    tr.set_image(None)
+    tr.render(1, 150)
+    okw = {k: v for k, v in kw.items() if k == "direct_light"}
+    want, live = orc.render(sc, oracle_config(4, **okw), 1, 150)
+    st = tr.stats()
+    assert [st.live[k] for k in range(5)] == [int(v) for v in live]
+    assert np.array_equal(tr.image(), want)
+
+
 def test_accumulation_continues_from_host_image(pt, cornell200):
     """camera::image is in/out: rendering 2+3 iterations with a host round trip == 5 in one go."""
     tr = make_tracer(cornell200)
