@@ -374,6 +374,14 @@ int pt_scene_load(const char *path, pt_scene **out) {
     }
     if (!have_camera || s->eye.empty()) { pth::set_error("pt_scene_load: %s has no CAMERA block", path); delete s; return PT_ERR_PARSE; }
     if (s->objects.empty() || s->materials.empty()) { pth::set_error("pt_scene_load: %s has no objects or no materials", path); delete s; return PT_ERR_PARSE; }
+    // the reference indexes every per-frame array of every object with the camera's frame number
+    // (raytraceKernel.cu:184-188): an object with fewer frames than the camera is an out-of-bounds read there
+    for (size_t i = 0; i < s->objects.size(); ++i)
+        if (s->objects[i].xf.size() < s->eye.size()) {
+            pth::set_error("pt_scene_load: object %zu has %zu frame(s), the camera has %zu", i, s->objects[i].xf.size(), s->eye.size());
+            delete s;
+            return PT_ERR_PARSE;
+        }
     for (size_t i = 0; i < s->objects.size(); ++i)
         if (s->objects[i].material < 0 || s->objects[i].material >= (int)s->materials.size()) {
             pth::set_error("pt_scene_load: object %zu references material %d (have %zu)", i, s->objects[i].material, s->materials.size());
