@@ -1508,6 +1508,9 @@ void free_scene_buffers(pt_context *c) {
     c->scene_ready = false;
 }
 
+// Every clear of device memory goes through hipMemsetAsync on the context's stream: that stream is
+// created non-blocking, so a hipMemset on the null stream would NOT be ordered against the kernels
+// launched here (it once wiped the primary-hit hook's output after the kernel had written it).
 // Conservative world-space AABB of a primitive for the culling pass (double precision, then
 // inflated).  Box: the 8 transformed corners of [-.5,.5]^3.  Sphere (an ellipsoid after the affine
 // map): centre +- 0.5*|row_k of the linear part|.  The inflation has to stay below RAY_BIAS_AMOUNT
@@ -1816,7 +1819,7 @@ int pt_create(const pt_config *cfg, pt_context **out) {
     if (c->rpt > 8) c->rpt = 8;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; pth::set_error("hipStreamCreate failed"); return PT_ERR_HIP; }
     if (hipMalloc(&c->d_sync, sizeof(SyncBlock)) != hipSuccess) { delete c; pth::set_error("hipMalloc(sync) failed"); return PT_ERR_HIP; }
-    (void)hipMemset(c->d_sync, 0, sizeof(SyncBlock));
+    (void)hipMemsetAsync(c->d_sync, 0, sizeof(SyncBlock), c->stream);
     *out = c;
     return PT_OK;
 }
@@ -1993,7 +1996,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         c->max_chunks = c->nseg;
         if (K > 1u || c->nee) {
             HIPCHK(hipMalloc(&c->d_planes, (size_t)K * W * H * 3 * sizeof(float)));
-            HIPCHK(hipMemset(c->d_planes, 0, (size_t)K * W * H * 3 * sizeof(float)));
+            HIPCHK(hipMemsetAsync(c->d_planes, 0, (size_t)K * W * H * 3 * sizeof(float), c->stream));
         }
         const uint32_t blocks_needed = (c->nseg + kWaves - 1) / kWaves;
         if ((uint32_t)grid > blocks_needed) grid = (int)blocks_needed;
@@ -2002,7 +2005,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         plan_levels(c, max_rays, c->lvl_slots, c->lvl_nseg);
         for (int i = 0; i < 2; ++i) {
             HIPCHK(hipMalloc(&c->d_segcnt[i], (size_t)(c->nseg + 2u) * 2 * sizeof(uint32_t)));     // [bin 0 | bin 1]
-            HIPCHK(hipMemset(c->d_segcnt[i], 0, (size_t)(c->nseg + 2u) * 2 * sizeof(uint32_t)));
+            HIPCHK(hipMemsetAsync(c->d_segcnt[i], 0, (size_t)(c->nseg + 2u) * 2 * sizeof(uint32_t), c->stream));
         }
         c->status_words = 0;
     } else {
@@ -2012,14 +2015,14 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         if ((uint32_t)grid > c->max_chunks) grid = (int)c->max_chunks;
         c->status_words = (uint32_t)c->cfg.max_depth * c->max_chunks;
         HIPCHK(hipMalloc(&c->d_status, (size_t)c->status_words * sizeof(u64)));
-        HIPCHK(hipMemset(c->d_status, 0, (size_t)c->status_words * sizeof(u64)));
+        HIPCHK(hipMemsetAsync(c->d_status, 0, (size_t)c->status_words * sizeof(u64), c->stream));
     }
     if (grid < 1) grid = 1;
     c->grid_bounce = grid;
 
     for (int i = 0; i < 2; ++i) HIPCHK(hipMalloc(&c->pool[i], (size_t)c->cap * kPoolFields * sizeof(float)));
     HIPCHK(hipMalloc(&c->image_own, (size_t)W * H * 3 * sizeof(float)));
-    HIPCHK(hipMemset(c->image_own, 0, (size_t)W * H * 3 * sizeof(float)));
+    HIPCHK(hipMemsetAsync(c->image_own, 0, (size_t)W * H * 3 * sizeof(float), c->stream));
     if (!c->image) c->image = c->image_own;
     HIPCHK(hipMalloc(&c->d_geoms, (size_t)G * sizeof(GeomRec)));
     HIPCHK(hipMalloc(&c->d_mats, (size_t)M * sizeof(MatRec)));
@@ -2037,7 +2040,7 @@ int pt_set_image(pt_context *c, const float *host_rgb) {
     HIPCHK(hipStreamSynchronize(c->stream));
     const size_t bytes = (size_t)c->W * c->H * 3 * sizeof(float);
     if (host_rgb) HIPCHK(hipMemcpy(c->image, host_rgb, bytes, hipMemcpyHostToDevice));
-    else HIPCHK(hipMemset(c->image, 0, bytes));
+    else HIPCHK(hipMemsetAsync(c->image, 0, bytes, c->stream));
     return PT_OK;
 }
 
@@ -2143,7 +2146,7 @@ int pt_reset_stats(pt_context *c) {
     if (!c) { pth::set_error("pt_reset_stats: null context"); return PT_ERR_ARGUMENT; }
     int rc = pt_sync(c);
     if (rc) return rc;
-    HIPCHK(hipMemset(c->d_sync, 0, sizeof(SyncBlock)));
+    HIPCHK(hipMemsetAsync(c->d_sync, 0, sizeof(SyncBlock), c->stream));
     c->counts_pending = false;
     c->ms[0] = c->ms[1] = c->ms[2] = 0;
     c->launches[0] = c->launches[1] = c->launches[2] = 0;
@@ -2169,7 +2172,7 @@ int pt_debug_primary_hits(pt_context *c, float *dir, int *hit, float *t, float *
     int *d_hit = nullptr;
     HIPCHK(hipMalloc(&d_dir, n * 12)); HIPCHK(hipMalloc(&d_P, n * 12)); HIPCHK(hipMalloc(&d_N, n * 12));
     HIPCHK(hipMalloc(&d_t, n * 4)); HIPCHK(hipMalloc(&d_hit, n * 4));
-    HIPCHK(hipMemset(d_hit, 0xFF, n * 4));
+    HIPCHK(hipMemsetAsync(d_hit, 0xFF, n * 4, c->stream));
     FlatArgs f;
     memset(&f, 0, sizeof f);
     f.cam = c->cam; f.image = c->image; f.geoms = c->d_geoms; f.mats = c->d_mats; f.G = c->G; f.M = c->M;
@@ -2201,7 +2204,7 @@ int pt_debug_trace_pool(pt_context *c, int iteration, int bounces, int *count, f
     const uint32_t bank_saved = c->bank;
     float *saved = c->image, *scratch = nullptr;
     HIPCHK(hipMalloc(&scratch, (size_t)c->W * c->H * 3 * sizeof(float)));
-    HIPCHK(hipMemset(scratch, 0, (size_t)c->W * c->H * 3 * sizeof(float)));
+    HIPCHK(hipMemsetAsync(scratch, 0, (size_t)c->W * c->H * 3 * sizeof(float), c->stream));
     c->image = scratch;
     int rc = enqueue_iterations(c, (uint32_t)iteration, 1u, bounces);
     c->image = saved;
