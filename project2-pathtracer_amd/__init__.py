@@ -17,7 +17,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libptmi355.so")
+# PTMI355_LIB: load another build of the same library (compiler-flag experiments, tools/flag_sweep.sh)
+LIB_PATH = os.environ.get("PTMI355_LIB") or os.path.join(_HERE, "libptmi355.so")
 
 
 class PtError(RuntimeError):
