@@ -273,11 +273,15 @@ def main():
                     traffic = round(per_step * args.steps / launches) if per_step else None
                     vi = rec.get("valu_wave_instructions_per_step")
                     if vi:
-                        # secondary bound: wave64 VALU issue, 1024 SIMDs x 2.4 GHz / 2 cycles
+                        # secondary bound: wave64 VALU issue.  The non-packed f32 rate behind the
+                        # guide's 78.6 TFLOP/s is one wave64 instruction per 4 cycles per SIMD (16 lanes/clk);
+                        # plain mul/add/mov issue in ~2 cycles (tools/ubench/pk_rate.hip), the hard ceiling.
                         rate = vi * args.steps / (stats.bounce_ms * 1e-3)
                         valu = {"wave_instructions_per_step": vi, "achieved_G_wave_inst_per_s": round(rate / 1e9, 1),
                                 "peak_G_wave_inst_per_s": 1228.8, "frac": round(rate / 1.2288e12, 4),
-                                "note": "instruction count from rocprofv3 SQ_INSTS_VALU (profiles/), duration live"}
+                                "frac_of_4_cycle_issue": round(rate / 0.6144e12, 4),
+                                "note": "instruction count from rocprofv3 SQ_INSTS_VALU (profiles/), duration live; peak = 1024 SIMDs x 2.4 GHz / 2 cycles, "
+                                        "frac_of_4_cycle_issue = against one wave64 instruction per 4 cycles per SIMD (the non-packed f32 rate)"}
                 except Exception:
                     traffic = None
             roof = {"bound": "hbm", "kernel": "k_bounce_defer / k_bounce_seg (cull + exact tests + scatter + accumulate + segmented compaction; bounce 0 also generates)",
