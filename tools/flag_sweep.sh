@@ -1,6 +1,11 @@
 #!/bin/bash
 # tools/flag_sweep.sh: bench every library build under project2-pathtracer_amd/build/variants/*.so
 # (compiler-flag experiments built on the CPU box) next to the in-tree build; one line per build.
+# Build a variant with e.g.
+#   cd project2-pathtracer_amd && mkdir -p build/variants && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC \
+#     -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -fno-slp-vectorize -w -shared \
+#     csrc/pt_kernels.hip csrc/pt_scene.cpp <extra flags> -o build/variants/<tag>.so
+# (build/ is git-ignored but travels to the GPU box with the snapshot); PTMI355_LIB selects the library.
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 for lib in "" $ROOT/project2-pathtracer_amd/build/variants/*.so; do
   for o in 1 0; do
