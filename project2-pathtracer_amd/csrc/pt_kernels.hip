@@ -236,6 +236,91 @@ __device__ __forceinline__ int nearest_hit_culled(const GeomRec *lg, const GeomR
     return hit;
 }
 
+// Many-primitive variant (33..256 primitives).  nearest_hit_culled runs its two exact-test loops once per
+// block of 32 primitives, so a 256-primitive scene pays ~13 mostly empty lock-step rounds per 64-ray group.
+// Here the wave-uniform scan fills eight mask registers (same 2 instructions per primitive), the masks are
+// turned into two packed per-lane index lists (cubes / spheres, 8 bits per entry, up to 8 entries each,
+// nearest candidate first -- ~10 instructions per set bit, no LDS), and the exact loops run ONCE over the
+// lists: ~5 rounds.  A wave in which any lane has more than 8 candidates of a type takes the block-wise
+// path, so the result is always the reference's.
+template <bool GEOM_LDS>
+__device__ __forceinline__ int nearest_hit_wide(const GeomRec *lg, const GeomRec *__restrict__ gg, int G, f3 o, f3 d,
+                                                float &tbest, f3 &P, f3 &N) {
+    const GeomRec *tab = GEOM_LDS ? lg : gg;
+    const CullRay cr = make_cull_ray(o, d);
+    uint32_t m[8], boxw[8], sphw[8];
+    float near_t[2] = {3.0e38f, 3.0e38f};
+    int near_p[2] = {-1, -1};
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        uint32_t mask = 0u, bb = 0u, sb = 0u;
+        const int base = w * 32;
+        const int n = base >= G ? 0 : ((G - base) < 32 ? (G - base) : 32);
+        for (int j = 0; j < n; ++j) {                     // wave-uniform index: broadcast loads
+            const GeomRec &g = tab[base + j];
+            const int type = g.type;
+            float tn;
+            bool keep;
+            if (type == 1) { bb |= 1u << j; keep = cull_box(g.bmin, g.bmax, cr, tn); }
+            else if (type == 0) { sb |= 1u << j; keep = cull_sphere(g.bmin, g.bmax, cr, tn); }
+            else continue;
+            if (keep) {
+                mask |= 1u << j;
+                const int ty = type == 1 ? 0 : 1;
+                if (tn < near_t[ty]) { near_t[ty] = tn; near_p[ty] = base + j; }
+            }
+        }
+        m[w] = mask; boxw[w] = bb; sphw[w] = sb;
+    }
+    // masks -> packed lists; entry 0 is kept for the nearest candidate of the type
+    uint32_t lo[2] = {0u, 0u}, hi[2] = {0u, 0u}, cnt[2] = {0u, 0u};
+    bool overflow = false;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            uint32_t mm = m[w] & (pass == 0 ? boxw[w] : sphw[w]);
+            while (mm) {
+                const uint32_t p = (uint32_t)(w * 32 + __builtin_ctz(mm));
+                mm &= mm - 1u;
+                if ((int)p == near_p[pass]) continue;
+                const uint32_t pos = cnt[pass] + 1u;
+                if (pos < 4u) lo[pass] |= p << (8u * pos);
+                else if (pos < 8u) hi[pass] |= p << (8u * (pos - 4u));
+                else overflow = true;
+                cnt[pass] = pos;
+            }
+        }
+    }
+    if (__any(overflow)) return nearest_hit_culled<GEOM_LDS>(lg, gg, G, o, d, tbest, P, N);
+    float best = 100000000000000000.0f;
+    int hit = -1;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const bool have = near_p[pass] >= 0;
+        const uint32_t total = have ? cnt[pass] + 1u : 0u;
+        const uint32_t l0 = lo[pass] | (have ? (uint32_t)near_p[pass] : 0u), l1 = hi[pass];
+        for (uint32_t i = 0; i < total; ++i) {            // per-lane trip count; the wave runs until all lanes are done
+            const int p = (int)(((i < 4u) ? (l0 >> (8u * i)) : (l1 >> (8u * (i - 4u)))) & 0xFFu);
+            const GeomRec *g = tab + p;                   // per-lane gather
+            if (hit >= 0) {                               // entered farther than the best exact hit: cannot win or tie
+                float tn;
+                if (pass == 0) (void)cull_box(g->bmin, g->bmax, cr, tn);
+                else (void)cull_sphere(g->bmin, g->bmax, cr, tn);
+                if (tn - g->slack > best) continue;
+            }
+            f3 pp, nn;
+            const float depth = pass == 0 ? box_test(g->inv, g->xf, g->inside_hits, o, d, pp, nn)
+                                          : sphere_test(g->inv, g->xf, o, d, pp, nn);
+            if (depth > -PT_EPSILON && (depth < best || (depth == best && p < hit))) {
+                best = depth; hit = p; P = pp; N = nn;
+            }
+        }
+    }
+    tbest = best;
+    return hit;
+}
+
 // Dynamic LDS layout (all scratch lives in the dynamic region so that its base stays 16-byte
 // aligned): [0,64) control words | material table | geometry table (LDS path) | ray stage.
 constexpr uint32_t kCtrlBytes = 64;
@@ -319,14 +404,15 @@ __device__ __forceinline__ bool shade_hit(const MatRec m, f3 P, f3 N, int bounce
     return code <= 2;
 }
 
-template <bool GEOM_LDS, bool LAST, bool CULL>
+template <bool GEOM_LDS, bool LAST, bool CULL, bool WIDE = false>
 __device__ __forceinline__ bool bounce_ray(const GeomRec *lg, const GeomRec *__restrict__ geoms, const MatRec *lm,
                                            int G, int bounce, uint32_t iteration, float *image, uint32_t pixel,
                                            f3 &o, f3 &d, f3 &thr, uint32_t &emitted) {
     float t;
     f3 P, N;
     int hit;
-    if (CULL) hit = nearest_hit_culled<GEOM_LDS>(lg, geoms, G, o, d, t, P, N);
+    if (CULL && WIDE) hit = nearest_hit_wide<GEOM_LDS>(lg, geoms, G, o, d, t, P, N);
+    else if (CULL) hit = nearest_hit_culled<GEOM_LDS>(lg, geoms, G, o, d, t, P, N);
     else if (GEOM_LDS) hit = nearest_hit(lg, G, o, d, t, P, N);
     else hit = nearest_hit(geoms, G, o, d, t, P, N);
     if (hit < 0) return false;
@@ -549,10 +635,11 @@ struct SegArgs {
     CamRec cam;
 };
 
-template <bool GEOM_LDS, bool LAST, bool CULL, bool GEN, bool NEE = false>
-__global__ __launch_bounds__(kBlock, NEE ? 4 : PT_SEG_WAVES) void k_bounce_seg(SegArgs a, const GeomRec *__restrict__ geoms,
+template <bool GEOM_LDS, bool LAST, bool CULL, bool GEN, bool NEE = false, bool WIDE = false>
+__global__ __launch_bounds__(kBlock, (NEE || WIDE) ? 4 : PT_SEG_WAVES) void k_bounce_seg(SegArgs a, const GeomRec *__restrict__ geoms,
                                                        const MatRec *__restrict__ mats) {
     static_assert(!NEE || (GEOM_LDS && CULL), "direct_light runs on the LDS tables with culling");
+    static_assert(!WIDE || (GEOM_LDS && CULL && !NEE), "the many-primitive variant runs on the LDS tables with culling");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *ctrl = reinterpret_cast<uint32_t *>(smem);   // [0] survivors, [1] emitted (block sums)
     if (threadIdx.x < 2) ctrl[threadIdx.x] = 0u;
@@ -631,7 +718,7 @@ __global__ __launch_bounds__(kBlock, NEE ? 4 : PT_SEG_WAVES) void k_bounce_seg(S
                     pixel |= (slot << 24) | (flag << 31);
                 } else {
                     float *acc = a.batch > 1u ? a.planes + (size_t)slot * a.plane_stride : a.image;
-                    alive = bounce_ray<GEOM_LDS, LAST, CULL>(lg, geoms, lm, a.G, a.bounce, a.iteration + slot, acc, pixel, o, d, thr, emitted);
+                    alive = bounce_ray<GEOM_LDS, LAST, CULL, WIDE>(lg, geoms, lm, a.G, a.bounce, a.iteration + slot, acc, pixel, o, d, thr, emitted);
                     pixel |= slot << 24;
                 }
             }
@@ -1434,6 +1521,7 @@ struct pt_context {
     uint32_t bank = 0;               // counter bank of the iteration being enqueued (fused segmented path)
     uint32_t batch_max = 1;          // iterations that may share one launch group
     float *d_planes = nullptr;       // batch_max accumulator planes (W*H*3 floats each)
+    bool wide = false;               // 33..256 primitives in LDS: k_bounce_seg<.., WIDE> (mask registers -> packed candidate lists)
     bool nee = false;                // cfg.direct_light: shadow rays at diffuse hits (k_bounce_seg<.., NEE>)
     uint32_t *d_lights = nullptr;    // indices of the emitting primitives
     uint32_t nlights = 0;
@@ -1642,6 +1730,14 @@ int launch_seg_lc(pt_context *c, const SegArgs &a, bool last, bool gen) {
 }
 
 template <bool LAST, bool GEN>
+int launch_wide_t(pt_context *c, const SegArgs &a) {
+    hipLaunchKernelGGL((k_bounce_seg<true, LAST, true, GEN, false, true>), dim3(c->grid_bounce), dim3(kBlock), c->lds_bytes, c->stream, a,
+                       (const GeomRec *)c->d_geoms, (const MatRec *)c->d_mats);
+    HIPCHK(hipGetLastError());
+    return PT_OK;
+}
+
+template <bool LAST, bool GEN>
 int launch_nee_t(pt_context *c, const SegArgs &a) {
     hipLaunchKernelGGL((k_bounce_seg<true, LAST, true, GEN, true>), dim3(c->grid_bounce), dim3(kBlock), c->lds_bytes, c->stream, a,
                        (const GeomRec *)c->d_geoms, (const MatRec *)c->d_mats);
@@ -1682,6 +1778,10 @@ int launch_seg(pt_context *c, const SegArgs &a, bool last, bool gen) {
     if (c->defer) {
         if (gen) return last ? launch_defer_t<true, true>(c, a) : launch_defer_t<false, true>(c, a);
         return last ? launch_defer_t<true, false>(c, a) : launch_defer_t<false, false>(c, a);
+    }
+    if (c->wide) {
+        if (gen) return last ? launch_wide_t<true, true>(c, a) : launch_wide_t<false, true>(c, a);
+        return last ? launch_wide_t<true, false>(c, a) : launch_wide_t<false, false>(c, a);
     }
     if (c->cull) return c->geom_lds ? launch_seg_lc<true, true>(c, a, last, gen) : launch_seg_lc<false, true>(c, a, last, gen);
     return c->geom_lds ? launch_seg_lc<true, false>(c, a, last, gen) : launch_seg_lc<false, false>(c, a, last, gen);
@@ -1930,6 +2030,9 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         tb = tables_bytes(G, M, false);
     }
     c->lds_bytes = c->use_bvh ? bvh_lds_bytes(G, M, c->nnodes) : tb + stage_bytes;
+    // 33..256 primitives with the table in LDS: the mask-register / packed-list variant (PT_WIDE=0 turns it off)
+    c->wide = c->cull && c->geom_lds && !c->nee && !c->use_bvh && !c->defer && !c->binned && c->cfg.mode == 0 && G > 32 && G <= 256;
+    if (const char *wv = getenv("PT_WIDE")) if (atoi(wv) == 0) c->wide = false;
     const void *fns[8] = {
         reinterpret_cast<const void *>(&k_bounce<true, false>), reinterpret_cast<const void *>(&k_bounce<false, false>),
         reinterpret_cast<const void *>(&k_bounce<true, true>), reinterpret_cast<const void *>(&k_bounce<false, true>),
@@ -1946,6 +2049,10 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         reinterpret_cast<const void *>(&k_bounce_seg<true, false, true, false, true>), reinterpret_cast<const void *>(&k_bounce_seg<true, true, true, false, true>),
         reinterpret_cast<const void *>(&k_bounce_seg<true, false, true, true, true>), reinterpret_cast<const void *>(&k_bounce_seg<true, true, true, true, true>)};
     if (c->lds_bytes > 64u * 1024u) {
+        const void *wide_fns[4] = {
+            reinterpret_cast<const void *>(&k_bounce_seg<true, false, true, false, false, true>), reinterpret_cast<const void *>(&k_bounce_seg<true, true, true, false, false, true>),
+            reinterpret_cast<const void *>(&k_bounce_seg<true, false, true, true, false, true>), reinterpret_cast<const void *>(&k_bounce_seg<true, true, true, true, false, true>)};
+        for (const void *fn : wide_fns) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         for (const void *fn : nee_fns) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         for (const void *fn : fns) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         for (const void *fn : gen_fns) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1955,7 +2062,8 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     int per_cu = c->cfg.blocks_per_cu;
     if (per_cu <= 0) {
         int occ = 0;
-        const void *fn = c->nee ? nee_fns[0]
+        const void *fn = c->wide ? reinterpret_cast<const void *>(&k_bounce_seg<true, false, true, false, false, true>)
+                       : c->nee ? nee_fns[0]
                        : c->binned ? reinterpret_cast<const void *>(&k_bounce_bin<false, false>)
                        : c->use_bvh ? reinterpret_cast<const void *>(&k_bounce_bvh<false, false>)
                        : c->defer ? reinterpret_cast<const void *>(&k_bounce_defer<false, false>) : fns[(c->seg_mode ? 4 : 0) + (c->geom_lds ? 0 : 1)];
