@@ -159,6 +159,9 @@ def main():
     ap.add_argument("--compaction", type=int, default=0, help="0 = segmented (default), 1 = look-back scan")
     ap.add_argument("--exchange", default="gather", choices=["gather", "reduce"],
                     help="N > 1 frame exchange: gather = owned rows to rank 0 (default), reduce = full-frame sum")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="contexts per GPU, each on its own HIP stream and owning every (streams*gpus)-th row: the tails of one "
+                         "context's launches are filled by the other's (bit-identical, like the multi-GPU sharding); 1 = off")
     ap.add_argument("--direct-light", type=int, default=0, help="1 = next-event estimation (one shadow ray per diffuse hit); not the headline configuration")
     args = ap.parse_args()
 
@@ -199,13 +202,58 @@ def main():
     geoms, mats, cam = sf.flatten(0)
     W, H = int(cam.resolution[0]), int(cam.resolution[1])
 
-    tracer = pkg.PathTracer(pkg.default_config(device=device, max_depth=depth, row_offset=rank, row_stride=world,
-                                               geometry_path=args.geometry_path, chunk_rays=args.chunk_rays,
-                                               blocks_per_cu=args.blocks_per_cu, culling=args.culling, merge_floor=args.merge_floor, batch=args.batch, ordering=args.ordering, bvh=args.bvh,
-                                               compaction=args.compaction, direct_light=args.direct_light, **options))
-    tracer.upload(geoms, mats, cam)
+    # S contexts per GPU: context r of rank k owns rows y with y % (world*S) == k + r*world -- together exactly
+    # the rows of rank k -- and all of them render straight into the same device accumulator.
+    S = max(1, args.streams)
     accum = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda:%d" % device)
-    tracer.bind_device_image(accum)
+    tracers = []
+    for r in range(S):
+        t = pkg.PathTracer(pkg.default_config(device=device, max_depth=depth, row_offset=rank + r * world, row_stride=world * S,
+                                              geometry_path=args.geometry_path, chunk_rays=args.chunk_rays,
+                                              blocks_per_cu=args.blocks_per_cu, culling=args.culling, merge_floor=args.merge_floor, batch=args.batch, ordering=args.ordering, bvh=args.bvh,
+                                              compaction=args.compaction, direct_light=args.direct_light, **options))
+        t.upload(geoms, mats, cam)
+        t.bind_device_image(accum)
+        tracers.append(t)
+
+    class Tracers:
+        """the S contexts driven as one: every call enqueues on all of them before any is awaited"""
+        def render(self, first, count):
+            for t in tracers:
+                t.render(first, count)
+
+        def sync(self):
+            for t in tracers:
+                t.sync()
+
+        def reset_stats(self):
+            for t in tracers:
+                t.reset_stats()
+
+        def set_profiling(self, on):
+            for t in tracers:
+                t.set_profiling(on)
+
+        def stats(self):
+            import types
+            parts = [t.stats() for t in tracers]
+            out = types.SimpleNamespace()
+            out.live = [sum(int(p.live[k]) for p in parts) for k in range(65)]
+            out.emitted = sum(int(p.emitted) for p in parts)
+            out.iterations = max(int(p.iterations) for p in parts)
+            out.bounce_launches = sum(int(p.bounce_launches) for p in parts)
+            # one stream: the summed HIP-event durations of the bounce launches.  Several streams: their launches
+            # overlap, so per-kernel durations cannot be added up; the busy time is then taken as the wall time
+            # of the whole event-bracketed pass (set by the caller: conservative, it includes k_fold and gaps)
+            out.bounce_ms = float(parts[0].bounce_ms) if len(parts) == 1 else 0.0
+            out.bounce_ms_sum = sum(float(p.bounce_ms) for p in parts)
+            return out
+
+        def close(self):
+            for t in tracers:
+                t.close()
+
+    tracer = Tracers()
 
     def barrier():
         if world > 1:
@@ -254,6 +302,8 @@ def main():
         elapsed_events = timed_pass(args.warmup + 1, True)
 
     stats = tracer.stats()
+    if S > 1 and elapsed_events:
+        stats.bounce_ms = elapsed_events * 1e3       # rank 0's pass incl. fold and launch gaps (>= the union of the kernel intervals)
     nbytes, design_bytes, live = algorithmic_bytes(stats, depth, fused_generate=(args.compaction == 0))
     result = None
     if rank == 0:
@@ -261,7 +311,7 @@ def main():
         roof = None
         if stats.bounce_ms > 0 and stats.bounce_launches:
             launches = int(stats.bounce_launches)
-            avg_ms = stats.bounce_ms / launches
+            avg_ms = stats.bounce_ms_sum / launches          # durations as rocprofv3 sees them (streams overlap)
             achieved = nbytes / (stats.bounce_ms * 1e-3) / 1e9
             traffic = None
             valu = None
@@ -288,6 +338,8 @@ def main():
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": round(nbytes / launches), "avg_launch_us": round(avg_ms * 1e3, 2),
+                    "duration": ("sum of the HIP-event durations of the bounce launches" if S == 1 else
+                                 "wall time of the event-bracketed pass (streams overlap; includes k_fold and launch gaps)"),
                     "bytes_formula": "SURVEY.md 8(d): N0*40 + sum_k[N_k*40 + N_k+1*40 + (N_k-N_k+1)*24], from the device live-ray counters",
                     "design_moved": {"bytes_per_launch": round(design_bytes / launches),
                                      "achieved": round(design_bytes / (stats.bounce_ms * 1e-3) / 1e9, 1),
@@ -303,7 +355,7 @@ def main():
                        "rays_per_step": W * H, "sharding": "rows interleaved over %d GPU(s), 1 RCCL %s per frame" % (world, "gather of the owned rows" if args.exchange == "gather" else "reduce"),
                        "live_ray_bounces_per_step": round(sum(live[:depth]) / max(1, int(stats.iterations))),
                        "compaction": ("segmented, wave-autonomous; " + {0: "stable order (ordering=0)", 1: "sparse-work queue (ordering=1)", 2: "binned two-ended (ordering=2)"}[args.ordering]) if args.compaction == 0 else "global look-back scan",
-                       "direct_light": bool(args.direct_light),
+                       "direct_light": bool(args.direct_light), "streams_per_gpu": S,
                        "ms_per_step_with_kernel_events": round(elapsed_events / args.steps * 1e3, 4) if elapsed_events else None},
             "roofline": roof,
         }

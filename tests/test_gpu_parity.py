@@ -238,6 +238,42 @@ def test_row_sharded_contexts_sum_to_the_full_frame(pt, cornell200):
     assert np.array_equal(total, want)
 
 
+@pytest.mark.parametrize("contexts,kw", [(2, dict(ordering=1)), (3, dict()), (2, dict(direct_light=1))])
+def test_concurrent_contexts_share_one_device_image(pt, contexts, kw):
+    """What bench.py --streams does: several contexts on ONE device, each on its own stream and owning every
+    n-th row, all bound to the same device accumulator and enqueued before any is awaited.  Their launches
+    overlap on the GPU; the frame is the single-context frame bit for bit."""
+    # the shared accumulator comes from the HIP runtime the library itself is linked against (no torch here:
+    # a second HIP runtime in the process could not open the device)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    sc = orc.load_golden_scene("cornell_mirror").with_resolution(192, 108)
+    nbytes = 108 * 192 * 3 * 4
+    trs = [make_tracer(sc, depth=6, row_offset=r, row_stride=contexts, **kw) for r in range(contexts)]
+    dptr = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dptr), nbytes) == 0 and hip.hipMemset(dptr, 0, nbytes) == 0 and hip.hipDeviceSynchronize() == 0
+    for tr in trs:
+        assert pt.lib().pt_bind_device_image(tr._h, dptr) == 0
+    for first in (1, 21):
+        for tr in trs:
+            tr.render(first, 20)
+    for tr in trs:
+        tr.sync()
+    got = np.zeros((108, 192, 3), np.float32)
+    assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), dptr, nbytes, 2) == 0          # hipMemcpyDeviceToHost
+    okw = {k: v for k, v in kw.items() if k == "direct_light"}
+    want, live = orc.render(sc, oracle_config(6, **okw), 1, 40)
+    assert np.array_equal(got, want)
+    total = [sum(int(tr.stats().live[k]) for tr in trs) for k in range(7)]
+    assert total == [int(v) for v in live]
+    for tr in trs:
+        tr.close()
+    hip.hipFree(dptr)
+
+
 def test_empty_and_tiny_inputs(pt):
     """Edge cases: a scene whose rays all miss (live count drops to 0 after the first bounce), a
     2x2 frame, a frame narrower than one wave."""
