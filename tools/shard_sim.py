@@ -1,7 +1,7 @@
 """Per-rank cost of the row-sharded render as a function of the shard count, measured on ONE GPU:
-the context renders only the rows one rank of an N-GPU job would own (row_stride = N).  N x the per-step
-time against the 1-GPU step time OF THE SAME RUN is the compute-side strong-scaling efficiency (exchange
-excluded).  usage: python tools/shard_sim.py   (from the repo root, on the GPU box)"""
+the contexts render only the rows one rank of an N-GPU job would own.  N x the per-step time against the
+1-GPU step time OF THE SAME RUN is the compute-side strong-scaling efficiency (exchange excluded).
+usage: python tools/shard_sim.py [streams=2]   (contexts per rank, as bench.py --streams)"""
 import importlib
 import os
 import sys
@@ -10,24 +10,33 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("project2-pathtracer_amd")
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 sf = pkg.SceneFile(os.path.join(ROOT, "scenes", "cornell_mirror.txt"))
 g, m, cam = sf.flatten(0)
 base = {}
-for stride in (1, 2, 4, 8):
-    tr = pkg.PathTracer(pkg.default_config(max_depth=8, ordering=1, row_offset=0, row_stride=stride))
-    tr.upload(g, m, cam)
-    tr.set_image(None)
-    tr.render(1, 40)
-    tr.sync()
+for world in (1, 2, 4, 8):
+    trs = []
+    for r in range(S):                     # rank 0 of `world`: rows y % (world*S) == r*world
+        tr = pkg.PathTracer(pkg.default_config(max_depth=8, ordering=1, row_offset=r * world, row_stride=world * S))
+        tr.upload(g, m, cam)
+        tr.set_image(None)
+        trs.append(tr)
+    for tr in trs:
+        tr.render(1, 40)
+    for tr in trs:
+        tr.sync()
     for steps in (20, 200):
         best = 1e9
         for rep in range(3):
             t0 = time.perf_counter()
-            tr.render(41 + rep * steps, steps)
-            tr.sync()
+            for tr in trs:
+                tr.render(41 + rep * steps, steps)
+            for tr in trs:
+                tr.sync()
             best = min(best, (time.perf_counter() - t0) / steps * 1e3)
-        if stride == 1:
+        if world == 1:
             base[steps] = best
-        print("shards %d, %3d steps per call: %.4f ms/step per rank, x%d = %.4f ms, efficiency %.2f"
-              % (stride, steps, best, stride, best * stride, base[steps] / (best * stride)))
-    tr.close()
+        print("%d context(s) per rank, shards %d, %3d steps per call: %.4f ms/step per rank, x%d = %.4f ms, efficiency %.2f"
+              % (S, world, steps, best, world, best * world, base[steps] / (best * world)))
+    for tr in trs:
+        tr.close()
