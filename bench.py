@@ -142,8 +142,8 @@ def cpu_baseline(scene_path, depth, budget_s=15.0, options=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=192, help="timed iterations; the default is a whole number of launch groups (16 or 32 iterations each at 1080p)")
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events in the timed region")

@@ -8,7 +8,9 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-events $*"
+# 64 timed + 32 warm-up steps = three FULL launch groups per context (2 contexts x 32 iterations at 1080p), so the
+# per-kernel averages are comparable with the default bench run (200 steps = six full groups + a short one)
+BENCH="python3 $ROOT/bench.py --steps 64 --warmup 32 --no-cpu-baseline --no-kernel-events $*"
 cd /tmp
 echo "== kernel trace"; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- $BENCH > "$OUT/kt.log" 2>&1 || { echo "kernel trace failed"; tail -5 "$OUT/kt.log"; exit 1; }
 [ -n "${KT_ONLY:-}" ] && { echo "kernel trace only"; exit 0; }
