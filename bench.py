@@ -202,58 +202,16 @@ def main():
     geoms, mats, cam = sf.flatten(0)
     W, H = int(cam.resolution[0]), int(cam.resolution[1])
 
-    # S contexts per GPU: context r of rank k owns rows y with y % (world*S) == k + r*world -- together exactly
-    # the rows of rank k -- and all of them render straight into the same device accumulator.
+    # S streams per GPU (pt_config.streams): the context shards this rank's rows once more over S internal contexts,
+    # each on its own HIP stream, all rendering straight into the same device accumulator.
     S = max(1, args.streams)
     accum = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda:%d" % device)
-    tracers = []
-    for r in range(S):
-        t = pkg.PathTracer(pkg.default_config(device=device, max_depth=depth, row_offset=rank + r * world, row_stride=world * S,
-                                              geometry_path=args.geometry_path, chunk_rays=args.chunk_rays,
-                                              blocks_per_cu=args.blocks_per_cu, culling=args.culling, merge_floor=args.merge_floor, batch=args.batch, ordering=args.ordering, bvh=args.bvh,
-                                              compaction=args.compaction, direct_light=args.direct_light, **options))
-        t.upload(geoms, mats, cam)
-        t.bind_device_image(accum)
-        tracers.append(t)
-
-    class Tracers:
-        """the S contexts driven as one: every call enqueues on all of them before any is awaited"""
-        def render(self, first, count):
-            for t in tracers:
-                t.render(first, count)
-
-        def sync(self):
-            for t in tracers:
-                t.sync()
-
-        def reset_stats(self):
-            for t in tracers:
-                t.reset_stats()
-
-        def set_profiling(self, on):
-            for t in tracers:
-                t.set_profiling(on)
-
-        def stats(self):
-            import types
-            parts = [t.stats() for t in tracers]
-            out = types.SimpleNamespace()
-            out.live = [sum(int(p.live[k]) for p in parts) for k in range(65)]
-            out.emitted = sum(int(p.emitted) for p in parts)
-            out.iterations = max(int(p.iterations) for p in parts)
-            out.bounce_launches = sum(int(p.bounce_launches) for p in parts)
-            # one stream: the summed HIP-event durations of the bounce launches.  Several streams: their launches
-            # overlap, so per-kernel durations cannot be added up; the busy time is then taken as the wall time
-            # of the whole event-bracketed pass (set by the caller: conservative, it includes k_fold and gaps)
-            out.bounce_ms = float(parts[0].bounce_ms) if len(parts) == 1 else 0.0
-            out.bounce_ms_sum = sum(float(p.bounce_ms) for p in parts)
-            return out
-
-        def close(self):
-            for t in tracers:
-                t.close()
-
-    tracer = Tracers()
+    tracer = pkg.PathTracer(pkg.default_config(device=device, max_depth=depth, row_offset=rank, row_stride=world, streams=S,
+                                               geometry_path=args.geometry_path, chunk_rays=args.chunk_rays,
+                                               blocks_per_cu=args.blocks_per_cu, culling=args.culling, merge_floor=args.merge_floor, batch=args.batch, ordering=args.ordering, bvh=args.bvh,
+                                               compaction=args.compaction, direct_light=args.direct_light, **options))
+    tracer.upload(geoms, mats, cam)
+    tracer.bind_device_image(accum)
 
     def barrier():
         if world > 1:
@@ -301,7 +259,13 @@ def main():
     if not args.no_kernel_events:
         elapsed_events = timed_pass(args.warmup + 1, True)
 
-    stats = tracer.stats()
+    raw = tracer.stats()
+    import types
+    stats = types.SimpleNamespace(live=[int(raw.live[k]) for k in range(65)], emitted=int(raw.emitted), iterations=int(raw.iterations),
+                                  bounce_launches=int(raw.bounce_launches), bounce_ms=float(raw.bounce_ms))
+    # one stream: bounce_ms = the summed HIP-event durations of the bounce launches.  Several streams: the library
+    # reports the longest stream's sum (the launches overlap); every stream's sum spans about the same interval
+    stats.bounce_ms_sum = stats.bounce_ms * S
     if S > 1 and elapsed_events:
         stats.bounce_ms = elapsed_events * 1e3       # rank 0's pass incl. fold and launch gaps (>= the union of the kernel intervals)
     nbytes, design_bytes, live = algorithmic_bytes(stats, depth, fused_generate=(args.compaction == 0))

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PTMI355_ABI_VERSION 1
+#define PTMI355_ABI_VERSION 2
 
 typedef enum {
     PT_OK = 0,
@@ -120,6 +120,11 @@ typedef struct {
                                 radiance only for camera rays and after specular events.  Same expectation
                                 as mode 0 without it, far less noise for small lights.  Needs compaction=0,
                                 culling=0, geometry_path=0 (LDS tables); ordering/bvh are ignored. */
+    int   streams;           /* 1 = one HIP stream (default).  n > 1: the context shards its rows once more over n
+                                internal contexts, each on its own stream, all rendering into the same image and
+                                all enqueued before any is awaited: the tails of one stream's launches are filled
+                                by the others' (mode 0; bit-identical; parity hooks need 1).  DESIGN.md section 4. */
+    int   reserved[3];
 } pt_config;
 
 typedef struct pt_context pt_context;

@@ -47,7 +47,7 @@ class Config(C.Structure):     # == pt_config
                 ("antialias", C.c_int), ("aperture", C.c_float), ("focal_distance", C.c_float),
                 ("row_offset", C.c_int), ("row_stride", C.c_int), ("geometry_path", C.c_int),
                 ("chunk_rays", C.c_int), ("blocks_per_cu", C.c_int), ("profile", C.c_int),
-                ("compaction", C.c_int), ("culling", C.c_int), ("merge_floor", C.c_int), ("batch", C.c_int), ("ordering", C.c_int), ("bvh", C.c_int), ("direct_light", C.c_int)]
+                ("compaction", C.c_int), ("culling", C.c_int), ("merge_floor", C.c_int), ("batch", C.c_int), ("ordering", C.c_int), ("bvh", C.c_int), ("direct_light", C.c_int), ("streams", C.c_int), ("reserved", C.c_int * 3)]
 
 
 class Stats(C.Structure):      # == pt_stats

@@ -1522,6 +1522,9 @@ struct pt_context {
     uint32_t batch_max = 1;          // iterations that may share one launch group
     float *d_planes = nullptr;       // batch_max accumulator planes (W*H*3 floats each)
     bool wide = false;               // 33..256 primitives in LDS: k_bounce_seg<.., WIDE> (mask registers -> packed candidate lists)
+    // cfg.streams > 1: this context only owns the frame (image) and fans every call out to `subs`, one
+    // ordinary context per stream, each rendering every streams-th of this context's rows into that image
+    std::vector<pt_context *> subs;
     bool nee = false;                // cfg.direct_light: shadow rays at diffuse hits (k_bounce_seg<.., NEE>)
     uint32_t *d_lights = nullptr;    // indices of the emitting primitives
     uint32_t nlights = 0;
@@ -1883,6 +1886,23 @@ int check_device_error(pt_context *c) {
 
 }  // namespace
 
+// ---- cfg.streams > 1 ------------------------------------------------------------------------------
+// Row sharding inside one GPU ("Two contexts per GPU"): the sub-contexts are plain
+// contexts with row_offset/row_stride refined by the stream index; they share the parent's image.
+namespace multi {
+
+int for_all(pt_context *c, int (*fn)(pt_context *)) {
+    for (pt_context *s : c->subs) { int rc = fn(s); if (rc) return rc; }
+    return PT_OK;
+}
+
+int rebind(pt_context *c) {
+    for (pt_context *s : c->subs) { int rc = pt_bind_device_image(s, c->image); if (rc) return rc; }
+    return PT_OK;
+}
+
+}  // namespace multi
+
 extern "C" {
 
 int pt_device_count(void) {
@@ -1909,6 +1929,24 @@ int pt_create(const pt_config *cfg, pt_context **out) {
         pth::set_error("pt_create: device %d is %s; this library carries gfx950 code objects only", cfg->device, prop.gcnArchName);
         return PT_ERR_NO_DEVICE;
     }
+    if (cfg->streams > 1 && cfg->mode == 0) {
+        if (cfg->streams > 8) { pth::set_error("pt_create: streams %d not in 1..8", cfg->streams); return PT_ERR_ARGUMENT; }
+        pt_context *parent = new pt_context();
+        parent->cfg = *cfg;
+        if (hipStreamCreateWithFlags(&parent->stream, hipStreamNonBlocking) != hipSuccess) { delete parent; pth::set_error("hipStreamCreate failed"); return PT_ERR_HIP; }
+        for (int r = 0; r < cfg->streams; ++r) {
+            pt_config sub = *cfg;
+            sub.streams = 1;
+            sub.row_offset = cfg->row_offset + r * cfg->row_stride;
+            sub.row_stride = cfg->row_stride * cfg->streams;
+            pt_context *sc = nullptr;
+            int rc = pt_create(&sub, &sc);
+            if (rc) { pt_destroy(parent); return rc; }
+            parent->subs.push_back(sc);
+        }
+        *out = parent;
+        return PT_OK;
+    }
     pt_context *c = new pt_context();
     c->cfg = *cfg;
     c->n_cu = prop.multiProcessorCount;
@@ -1927,6 +1965,8 @@ int pt_create(const pt_config *cfg, pt_context **out) {
 void pt_destroy(pt_context *c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
+    for (pt_context *s : c->subs) pt_destroy(s);
+    c->subs.clear();
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_scene_buffers(c);
     if (c->d_sync) (void)hipFree(c->d_sync);
@@ -1938,6 +1978,21 @@ void pt_destroy(pt_context *c) {
 
 int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_material *mats, int M, const pt_camera *cam) {
     if (!c || !geoms || !mats || !cam || G < 1 || M < 1) { pth::set_error("pt_upload_scene: bad argument"); return PT_ERR_ARGUMENT; }
+    if (!c->subs.empty()) {
+        HIPCHK(hipSetDevice(c->cfg.device));
+        for (pt_context *s : c->subs) { int rc = pt_upload_scene(s, geoms, G, mats, M, cam); if (rc) return rc; }
+        const int W = c->subs[0]->W, H = c->subs[0]->H;
+        if (c->image_own && (W != c->W || H != c->H)) { (void)hipFree(c->image_own); if (c->image == c->image_own) c->image = nullptr; c->image_own = nullptr; }
+        c->W = W; c->H = H; c->G = G; c->M = M;
+        c->n_own = 0;
+        for (pt_context *s : c->subs) c->n_own += s->n_own;
+        if (!c->image_own) HIPCHK(hipMalloc(&c->image_own, (size_t)W * H * 3 * sizeof(float)));
+        HIPCHK(hipMemsetAsync(c->image_own, 0, (size_t)W * H * 3 * sizeof(float), c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (!c->image) c->image = c->image_own;
+        c->scene_ready = true;
+        return multi::rebind(c);
+    }
     HIPCHK(hipSetDevice(c->cfg.device));
     HIPCHK(hipStreamSynchronize(c->stream));
     const int W = (int)cam->resolution[0], H = (int)cam->resolution[1];
@@ -2145,10 +2200,12 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
 int pt_set_image(pt_context *c, const float *host_rgb) {
     if (!c || !c->scene_ready) { pth::set_error("pt_set_image: no scene uploaded"); return PT_ERR_STATE; }
     HIPCHK(hipSetDevice(c->cfg.device));
+    for (pt_context *s : c->subs) HIPCHK(hipStreamSynchronize(s->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     const size_t bytes = (size_t)c->W * c->H * 3 * sizeof(float);
     if (host_rgb) HIPCHK(hipMemcpy(c->image, host_rgb, bytes, hipMemcpyHostToDevice));
     else HIPCHK(hipMemsetAsync(c->image, 0, bytes, c->stream));
+    if (!c->subs.empty()) HIPCHK(hipStreamSynchronize(c->stream));        // the sub-contexts' streams do not order against it
     return PT_OK;
 }
 
@@ -2157,12 +2214,22 @@ int pt_bind_device_image(pt_context *c, void *device_rgb) {
     HIPCHK(hipSetDevice(c->cfg.device));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->image = device_rgb ? static_cast<float *>(device_rgb) : c->image_own;
+    if (!c->subs.empty()) {
+        for (pt_context *s : c->subs) HIPCHK(hipStreamSynchronize(s->stream));
+        if (c->image) return multi::rebind(c);
+    }
     return PT_OK;
 }
 
 int pt_get_image(pt_context *c, float *host_rgb) {
     if (!c || !c->scene_ready || !host_rgb) { pth::set_error("pt_get_image: bad state/argument"); return PT_ERR_STATE; }
     HIPCHK(hipSetDevice(c->cfg.device));
+    if (!c->subs.empty()) {
+        int rc = multi::for_all(c, pt_sync);
+        if (rc) return rc;
+        HIPCHK(hipMemcpy(host_rgb, c->image, (size_t)c->W * c->H * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        return PT_OK;
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(host_rgb, c->image, (size_t)c->W * c->H * 3 * sizeof(float), hipMemcpyDeviceToHost));
     return check_device_error(c);
@@ -2172,6 +2239,10 @@ int pt_render(pt_context *c, int first_iteration, int count) {
     if (!c || !c->scene_ready) { pth::set_error("pt_render: no scene uploaded"); return PT_ERR_STATE; }
     if (first_iteration < 1 || count < 0) { pth::set_error("pt_render: iterations are 1-based"); return PT_ERR_ARGUMENT; }
     HIPCHK(hipSetDevice(c->cfg.device));
+    if (!c->subs.empty()) {                      // enqueue on every stream before anything is awaited
+        for (pt_context *s : c->subs) { int rc = pt_render(s, first_iteration, count); if (rc) return rc; }
+        return PT_OK;
+    }
     for (int it = first_iteration; it < first_iteration + count; ++it) {
         if (c->cfg.mode == 1) {
             Scoped s(c, 1);
@@ -2197,6 +2268,7 @@ int pt_render(pt_context *c, int first_iteration, int count) {
 int pt_sync(pt_context *c) {
     if (!c) { pth::set_error("pt_sync: null context"); return PT_ERR_ARGUMENT; }
     HIPCHK(hipSetDevice(c->cfg.device));
+    if (!c->subs.empty()) return multi::for_all(c, pt_sync);
     HIPCHK(hipStreamSynchronize(c->stream));
     int rc = resolve_events(c);
     if (rc) return rc;
@@ -2207,6 +2279,10 @@ int pt_display(pt_context *c, float scale, void *out, int out_is_device) {
     if (!c || !c->scene_ready) { pth::set_error("pt_display: no scene uploaded"); return PT_ERR_STATE; }
     if (!out) return PT_OK;
     HIPCHK(hipSetDevice(c->cfg.device));
+    if (!c->subs.empty()) {                      // the whole frame lives in the shared image: any sub-context can show it
+        for (pt_context *s : c->subs) HIPCHK(hipStreamSynchronize(s->stream));
+        return pt_display(c->subs[0], scale, out, out_is_device);
+    }
     const uint32_t n = (uint32_t)c->W * c->H;
     uchar4 *dst = out_is_device ? static_cast<uchar4 *>(out) : c->d_display;
     {
@@ -2232,11 +2308,29 @@ int pt_set_profiling(pt_context *c, int enabled) {
     int rc = pt_sync(c);
     if (rc) return rc;
     c->cfg.profile = enabled ? 1 : 0;
+    for (pt_context *s : c->subs) s->cfg.profile = c->cfg.profile;
     return PT_OK;
 }
 
 int pt_get_stats(pt_context *c, pt_stats *out) {
     if (!c || !out) { pth::set_error("pt_get_stats: null argument"); return PT_ERR_ARGUMENT; }
+    if (!c->subs.empty()) {
+        // counters add up; the streams' launches overlap, so the busy time reported is the longest stream's
+        memset(out, 0, sizeof *out);
+        for (pt_context *s : c->subs) {
+            pt_stats p;
+            int rc = pt_get_stats(s, &p);
+            if (rc) return rc;
+            for (int k = 0; k < 65; ++k) out->live[k] += p.live[k];
+            out->emitted += p.emitted;
+            out->generate_launches += p.generate_launches; out->bounce_launches += p.bounce_launches; out->display_launches += p.display_launches;
+            if (p.generate_ms > out->generate_ms) out->generate_ms = p.generate_ms;
+            if (p.bounce_ms > out->bounce_ms) out->bounce_ms = p.bounce_ms;
+            if (p.display_ms > out->display_ms) out->display_ms = p.display_ms;
+            if (p.iterations > out->iterations) out->iterations = p.iterations;
+        }
+        return PT_OK;
+    }
     int rc = pt_sync(c);
     if (rc) return rc;
     SyncBlock h;
@@ -2252,6 +2346,7 @@ int pt_get_stats(pt_context *c, pt_stats *out) {
 
 int pt_reset_stats(pt_context *c) {
     if (!c) { pth::set_error("pt_reset_stats: null context"); return PT_ERR_ARGUMENT; }
+    if (!c->subs.empty()) return multi::for_all(c, pt_reset_stats);
     int rc = pt_sync(c);
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(c->d_sync, 0, sizeof(SyncBlock), c->stream));
@@ -2274,6 +2369,7 @@ int pt_get_resolution(pt_context *c, int *w, int *h, int *owned) {
 
 int pt_debug_primary_hits(pt_context *c, float *dir, int *hit, float *t, float *P, float *N) {
     if (!c || !c->scene_ready) { pth::set_error("pt_debug_primary_hits: no scene uploaded"); return PT_ERR_STATE; }
+    if (!c->subs.empty()) { pth::set_error("pt_debug_primary_hits: parity hooks need streams = 1"); return PT_ERR_STATE; }
     HIPCHK(hipSetDevice(c->cfg.device));
     const size_t n = (size_t)c->W * c->H;
     float *d_dir = nullptr, *d_t = nullptr, *d_P = nullptr, *d_N = nullptr;
@@ -2301,6 +2397,7 @@ int pt_debug_primary_hits(pt_context *c, float *dir, int *hit, float *t, float *
 int pt_debug_trace_pool(pt_context *c, int iteration, int bounces, int *count, float *ox, float *oy, float *oz,
                         float *dx, float *dy, float *dz, float *tr, float *tg, float *tb, uint32_t *pixel) {
     if (!c || !c->scene_ready || c->cfg.mode != 0) { pth::set_error("pt_debug_trace_pool: needs a path-trace context with a scene"); return PT_ERR_STATE; }
+    if (!c->subs.empty()) { pth::set_error("pt_debug_trace_pool: parity hooks need streams = 1"); return PT_ERR_STATE; }
     if (bounces < 0 || bounces > c->cfg.max_depth || iteration < 1) { pth::set_error("pt_debug_trace_pool: bad bounces/iteration"); return PT_ERR_ARGUMENT; }
     HIPCHK(hipSetDevice(c->cfg.device));
     // render into a scratch accumulator and restore the counters afterwards: the hook leaves image
@@ -2369,6 +2466,7 @@ int pt_debug_trace_pool(pt_context *c, int iteration, int bounces, int *count, f
 int pt_debug_rng_from_thread(pt_context *c, float resx, float resy, float time, int n, const int *xy, float *out3) {
     (void)resy;
     if (!c || n < 0 || !xy || !out3) { pth::set_error("pt_debug_rng_from_thread: bad argument"); return PT_ERR_ARGUMENT; }
+    if (!c->subs.empty()) return pt_debug_rng_from_thread(c->subs[0], resx, resy, time, n, xy, out3);
     if (n == 0) return PT_OK;
     HIPCHK(hipSetDevice(c->cfg.device));
     int *d_xy = nullptr; float *d_out = nullptr;
@@ -2384,6 +2482,7 @@ int pt_debug_rng_from_thread(pt_context *c, float resx, float resy, float time, 
 
 int pt_debug_hemisphere(pt_context *c, int n, const float *normal3, const float *xi2, float *out3) {
     if (!c || n < 0 || !normal3 || !xi2 || !out3) { pth::set_error("pt_debug_hemisphere: bad argument"); return PT_ERR_ARGUMENT; }
+    if (!c->subs.empty()) return pt_debug_hemisphere(c->subs[0], n, normal3, xi2, out3);
     if (n == 0) return PT_OK;
     HIPCHK(hipSetDevice(c->cfg.device));
     float *d_n = nullptr, *d_x = nullptr, *d_o = nullptr;
@@ -2399,6 +2498,7 @@ int pt_debug_hemisphere(pt_context *c, int n, const float *normal3, const float 
 }
 
 int pt_debug_light_points(pt_context *c, int geom, int n, const float *seeds, float *out3) {
+    if (c && !c->subs.empty()) return pt_debug_light_points(c->subs[0], geom, n, seeds, out3);
     if (!c || !c->scene_ready || geom < 0 || geom >= c->G || n < 0 || !seeds || !out3) { pth::set_error("pt_debug_light_points: bad argument"); return PT_ERR_ARGUMENT; }
     if (n == 0) return PT_OK;
     HIPCHK(hipSetDevice(c->cfg.device));
@@ -2415,6 +2515,7 @@ int pt_debug_light_points(pt_context *c, int geom, int n, const float *seeds, fl
 
 int pt_debug_sincos(pt_context *c, int n, const float *a, float *s, float *co) {
     if (!c || n < 0 || !a || !s || !co) { pth::set_error("pt_debug_sincos: bad argument"); return PT_ERR_ARGUMENT; }
+    if (!c->subs.empty()) return pt_debug_sincos(c->subs[0], n, a, s, co);
     if (n == 0) return PT_OK;
     HIPCHK(hipSetDevice(c->cfg.device));
     float *d_a = nullptr, *d_s = nullptr, *d_c = nullptr;

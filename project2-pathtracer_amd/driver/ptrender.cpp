@@ -15,7 +15,7 @@
 // back to the adaptor's environment variables:
 //   depth= (PT_MAX_DEPTH)  mode=pathtrace|reference (PT_MODE)  camera= (PT_CAMERA_MODE)  aa= (PT_AA)
 //   aperture= (PT_APERTURE)  focal= (PT_FOCAL_DIST)  gpus= (PT_NGPU)  device= (PT_DEVICE)
-//   devices=0,1,.. (PT_DEVICES: explicit ordinals, may repeat)  direct=0|1 (PT_DIRECT_LIGHT)
+//   devices=0,1,.. (PT_DEVICES: explicit ordinals, may repeat)  direct=0|1 (PT_DIRECT_LIGHT)  streams=<n> (PT_STREAMS, default 2)
 //   iterations=<n> overrides the scene's ITERATIONS, out=<dir> redirects the output directory,
 //   ordering=/batch= pass through to pt_config, raw=1 also writes <file>.f32 (the float sum).
 // Several GPUs: one context per device, rows interleaved, every device's work enqueued before any
@@ -40,7 +40,7 @@ struct Options {
     std::string scene, outdir, devices;
     int frame = 0;
     bool single_frame = false;
-    int depth, mode, camera_mode, aa, gpus, device, iterations = 0, ordering = -1, batch = -1, raw = 0, direct = 0;
+    int depth, mode, camera_mode, aa, gpus, device, iterations = 0, ordering = -1, batch = -1, raw = 0, direct = 0, streams = 2;
     float aperture, focal;
 };
 
@@ -69,6 +69,7 @@ int main(int argc, char **argv) {
     o.device = atoi(env_or("PT_DEVICE", "0"));
     o.devices = env_or("PT_DEVICES", "");
     o.direct = atoi(env_or("PT_DIRECT_LIGHT", "0"));
+    o.streams = atoi(env_or("PT_STREAMS", "2"));
     for (int i = 1; i < argc; ++i) {
         const std::string arg(argv[i]);
         const size_t eq = arg.find('=');
@@ -90,6 +91,7 @@ int main(int argc, char **argv) {
         else if (key == "batch") o.batch = atoi(val.c_str());
         else if (key == "raw") o.raw = atoi(val.c_str());
         else if (key == "direct") o.direct = atoi(val.c_str());
+        else if (key == "streams") o.streams = atoi(val.c_str());
         // unknown keys are ignored, like main.cpp's argument loop
     }
     if (o.scene.empty()) {
@@ -129,6 +131,7 @@ int main(int argc, char **argv) {
         cfg.aperture = o.aperture;
         cfg.focal_distance = o.focal;
         cfg.direct_light = o.direct;
+        cfg.streams = o.streams;
         cfg.row_offset = r;
         cfg.row_stride = o.gpus;
         if (o.ordering >= 0) cfg.ordering = o.ordering;

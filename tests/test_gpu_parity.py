@@ -274,6 +274,39 @@ def test_concurrent_contexts_share_one_device_image(pt, contexts, kw):
     hip.hipFree(dptr)
 
 
+@pytest.mark.parametrize("streams,kw,depth", [(2, dict(ordering=1), 8), (3, dict(), 6), (2, dict(direct_light=1), 6),
+                                               (2, dict(row_offset=1, row_stride=2, ordering=1), 6), (4, dict(batch=3), 5)])
+def test_streams_inside_one_context_are_bit_identical(pt, streams, kw, depth):
+    """pt_config.streams: the context shards its rows over internal contexts on separate streams sharing one image.
+    Image, live counts, display bytes and the host-image round trip equal the oracle / the one-stream context."""
+    sc = orc.load_golden_scene("cornell_mirror").with_resolution(160, 90)
+    tr = make_tracer(sc, depth=depth, streams=streams, **kw)
+    start = np.random.default_rng(9).random((90, 160, 3)).astype(np.float32)
+    tr.set_image(start)
+    tr.render(1, 7)
+    mid = tr.image()
+    tr.set_image(mid)
+    tr.render(8, 5)
+    okw = {k: v for k, v in kw.items() if k in ("direct_light", "row_offset", "row_stride")}
+    want, live = orc.render(sc, oracle_config(depth, **okw), 1, 12, image=start.copy())
+    got = tr.image()
+    assert np.array_equal(got, want)
+    st = tr.stats()
+    assert [st.live[k] for k in range(depth + 1)] == [int(v) for v in live]
+    assert tr.owned == sum(1 for y in range(90) if y % kw.get("row_stride", 1) == kw.get("row_offset", 0)) * 160
+    # sendImageToPBO over the shared frame
+    disp = tr.display(1.0 / 12)
+    ref = np.zeros((90 * 160, 4), np.uint8)
+    px = (C.c_uint8 * 4)()
+    flat = (want.reshape(-1, 3) * np.float32(1.0 / 12)).astype(np.float32)
+    for i in range(0, 90 * 160, 97):
+        orc.lib().orc_display_pixel(orc.vec3(*flat[i]), px)
+        assert list(disp.reshape(-1, 4)[i]) == list(px)
+    with pytest.raises(pt.PtError, match="streams = 1"):
+        tr.trace_pool(1, 1)
+    tr.close()
+
+
 def test_empty_and_tiny_inputs(pt):
     """Edge cases: a scene whose rays all miss (live count drops to 0 after the first bounce), a
     2x2 frame, a frame narrower than one wave."""
