@@ -26,6 +26,8 @@
 extern "C" {
 #endif
 
+/* 2: pt_config grew by `streams` + reserved[3] (1 ended at `direct_light`); always fill pt_config through
+ * pt_config_default() first, so that fields added later keep their defaults */
 #define PTMI355_ABI_VERSION 2
 
 typedef enum {
