@@ -307,6 +307,24 @@ def test_streams_inside_one_context_are_bit_identical(pt, streams, kw, depth):
     tr.close()
 
 
+def test_streams_survive_a_scene_change(pt):
+    """Re-uploading another scene at another resolution into a streams = 2 context (what the adaptor does when the
+    caller's scene content changes): buffers are rebuilt, the shared image is re-created and re-bound."""
+    a = orc.load_golden_scene("cornell_mirror").with_resolution(64, 48)
+    b = orc.load_golden_scene("sampleScene").with_resolution(96, 64)
+    tr = make_tracer(a, depth=5, streams=2, ordering=1)
+    tr.set_image(None)
+    tr.render(1, 3)
+    wa, _ = orc.render(a, oracle_config(5), 1, 3)
+    assert np.array_equal(tr.image(), wa)
+    tr.upload(*to_product(b))
+    tr.set_image(None)
+    tr.render(1, 4)
+    wb, live = orc.render(b, oracle_config(5), 1, 4)
+    assert tr.image().shape == (64, 96, 3) and np.array_equal(tr.image(), wb)
+    tr.close()
+
+
 def test_empty_and_tiny_inputs(pt):
     """Edge cases: a scene whose rays all miss (live count drops to 0 after the first bounce), a
     2x2 frame, a frame narrower than one wave."""
