@@ -120,6 +120,14 @@ def cpu_baseline(scene_path, depth, budget_s=15.0, options=None):
     W, H = int(cam.resolution[0]), int(cam.resolution[1])
     L = orc.lib()
     cores = L.orc_max_threads()
+    # threads actually usable here: the affinity mask and the cgroup CPU quota can be far below the core count
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+        quota = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota[0] != "max":
+            cores = max(1, min(cores, int(-(-int(quota[0]) // int(quota[1])))))
+    except Exception:
+        pass
     cfg = orc.default_config(depth, **(options or {}))
     img = np.zeros((H, W, 3), np.float32)
     live = np.zeros(depth + 1, np.uint64)
@@ -134,9 +142,23 @@ def cpu_baseline(scene_path, depth, budget_s=15.0, options=None):
     t1 = run(1, 1)
     n = max(1, min(64, int(budget_s / max(t1, 1e-3)) - 1))
     t = run(2, n)
-    return {"value": round(W * H * n * depth / t / 1e6, 3), "unit": "Mray/s", "cores": int(cores), "kind": "port",
-            "sample": "%d whole-frame iterations of the same workload (%dx%d, %d bounces) with oracle/pt_oracle.c, OpenMP over rows, %.1f s"
-                      % (n, W, H, depth, t)}
+    out = {"value": round(W * H * n * depth / t / 1e6, 3), "unit": "Mray/s", "cores": int(cores), "kind": "port",
+           "sample": "%d whole-frame iterations of the same workload (%dx%d, %d bounces) with oracle/pt_oracle.c, OpenMP over rows, %.1f s"
+                     % (n, W, H, depth, t)}
+    # SURVEY.md 8(d) also asks for the one-core figure: every 4th row of one iteration on a single thread
+    # (rows are independent, so the sample scales to the frame), a few seconds of work
+    one = orc.default_config(depth, **(options or {}))
+    one.row_offset, one.row_stride = 0, 4
+    img1 = np.zeros((H, W, 3), np.float32)
+    t0 = time.perf_counter()
+    rc = L.orc_render(og, len(og), om, len(om), C.byref(oc), C.byref(one), 1, 1, orc.fptr(img1),
+                      live.ctypes.data_as(C.POINTER(C.c_uint64)), 1)
+    assert rc == 0
+    t_one = time.perf_counter() - t0
+    rows = len(range(0, H, 4))
+    out["one_core"] = {"value": round(W * rows * depth / t_one / 1e6, 3), "unit": "Mray/s",
+                       "sample": "%d of %d rows of one iteration on one thread, %.1f s" % (rows, H, t_one)}
+    return out
 
 
 def main():
