@@ -27,8 +27,9 @@ extern "C" {
 #endif
 
 /* 2: pt_config grew by `streams` + reserved[3] (1 ended at `direct_light`); always fill pt_config through
- * pt_config_default() first, so that fields added later keep their defaults */
-#define PTMI355_ABI_VERSION 2
+ * pt_config_default() first, so that fields added later keep their defaults
+ * 3: + pt_get_rows, pt_gather_rows_peer (the per-frame exchange of a row-sharded render) */
+#define PTMI355_ABI_VERSION 3
 
 typedef enum {
     PT_OK = 0,
@@ -165,6 +166,15 @@ int  pt_set_image(pt_context *ctx, const float *host_rgb);
  * later reduced with RCCL); NULL returns to the internal buffer. */
 int  pt_bind_device_image(pt_context *ctx, void *device_rgb);
 int  pt_get_image(pt_context *ctx, float *host_rgb);       /* synchronises; the SUM over iterations */
+/* Row-sharded renders (row_offset/row_stride): copy ONLY the rows this context owns into the full-frame
+ * host image (W*H*3 floats; the other rows are left untouched), i.e. 1/row_stride of the frame over PCIe.
+ * Calling it on every context of an N-GPU render assembles camera::image (src/raytraceKernel.cu:215 downloads
+ * the whole frame from its one GPU).  Synchronises. */
+int  pt_get_rows(pt_context *ctx, float *host_rgb);
+/* The same exchange device to device: the rows `src` owns are copied into `dst`'s accumulator (peer copy over
+ * xGMI when the contexts sit on different GPUs; both contexts must hold the same resolution).  Afterwards
+ * `dst` can show or download the assembled frame (pt_display / pt_get_image).  Synchronises both. */
+int  pt_gather_rows_peer(pt_context *dst, pt_context *src);
 
 /* Enqueue iterations [first, first+count) (1-based like main.cpp:110) on the context's stream;
  * asynchronous.  Each adds one path per owned pixel into the accumulator. */

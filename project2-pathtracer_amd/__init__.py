@@ -84,6 +84,8 @@ def lib():
     L.pt_set_image.argtypes = [vp, fp]
     L.pt_bind_device_image.argtypes = [vp, vp]
     L.pt_get_image.argtypes = [vp, fp]
+    L.pt_get_rows.argtypes = [vp, fp]
+    L.pt_gather_rows_peer.argtypes = [vp, vp]
     L.pt_render.argtypes = [vp, C.c_int, C.c_int]
     L.pt_sync.argtypes = [vp]
     L.pt_display.argtypes = [vp, C.c_float, vp, C.c_int]
@@ -112,7 +114,7 @@ def lib():
 
 EXPORTS = [
     "pt_abi_version", "pt_last_error", "pt_config_default", "pt_device_count", "pt_create", "pt_destroy",
-    "pt_upload_scene", "pt_set_image", "pt_bind_device_image", "pt_get_image", "pt_render", "pt_sync",
+    "pt_upload_scene", "pt_set_image", "pt_bind_device_image", "pt_get_image", "pt_get_rows", "pt_gather_rows_peer", "pt_render", "pt_sync",
     "pt_display", "pt_set_profiling", "pt_get_stats", "pt_reset_stats", "pt_get_resolution", "pt_debug_primary_hits",
     "pt_debug_trace_pool", "pt_debug_rng_from_thread", "pt_debug_hemisphere", "pt_debug_sincos", "pt_debug_light_points",
     "pt_scene_load", "pt_scene_free", "pt_scene_counts", "pt_scene_image_name", "pt_scene_flatten",
@@ -216,6 +218,16 @@ class PathTracer:
         out = np.zeros((self.H, self.W, 3), np.float32)
         _check(lib().pt_get_image(self._h, _fp(out)))
         return out
+
+    def get_rows(self, out):
+        """Copy only the rows this context owns into the full-frame host array `out` (H, W, 3) float32."""
+        assert out.dtype == np.float32 and out.flags["C_CONTIGUOUS"] and out.size == self.W * self.H * 3
+        _check(lib().pt_get_rows(self._h, _fp(out)))
+        return out
+
+    def gather_rows_from(self, other):
+        """Device-to-device: copy the rows `other` owns into this context's accumulator (peer copy)."""
+        _check(lib().pt_gather_rows_peer(self._h, other._h))
 
     def display(self, scale=1.0):
         out = np.zeros((self.H, self.W, 4), np.uint8)

@@ -51,6 +51,8 @@ int g_mode = 0;
 // result (pos != NULL, final iteration, PT_SYNC_EVERY_CALL) or when the scene changes.  What main.cpp
 // can see (camera::image after the last iteration, src/main.cpp:136-147) is unchanged.
 int g_pending_first = 0, g_pending_count = 0;
+// options read from the environment ONCE, when the contexts are created (not per call)
+int g_sync_every_call = 0, g_lazy = 1, g_pbo_is_device = 0;
 
 void flush_pending() {
     if (g_pending_count > 0) {
@@ -105,17 +107,14 @@ namespace {
 // camera::image <- the rows each context owns (every context started from the same host image, so a
 // row's owner holds initial value + all of that row's samples)
 void gather_image(float *host, int W, int H) {
-    const size_t N = g_ctxs.size();
-    if (N == 1) {
+    (void)W; (void)H;
+    if (g_ctxs.size() == 1) {
         if (pt_get_image(g_ctxs[0], host) != PT_OK) die("Kernel failed!");
         return;
     }
-    std::vector<float> tmp((size_t)W * H * 3);
-    for (size_t r = 0; r < N; ++r) {
-        if (pt_get_image(g_ctxs[r], tmp.data()) != PT_OK) die("Kernel failed!");
-        for (int y = (int)r; y < H; y += (int)N)
-            memcpy(host + (size_t)y * W * 3, tmp.data() + (size_t)y * W * 3, (size_t)W * 3 * sizeof(float));
-    }
+    // N GPUs: each sends only its own rows (1/N of the frame over its own PCIe link)
+    for (pt_context *c : g_ctxs)
+        if (pt_get_rows(c, host) != PT_OK) die("Kernel failed!");
 }
 
 }  // namespace
@@ -153,6 +152,9 @@ void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iteratio
             if (pt_create(&cfg, &c) != PT_OK) die("pt_create");
             g_ctxs.push_back(c);
         }
+        g_sync_every_call = env_int("PT_SYNC_EVERY_CALL", 0);
+        g_lazy = env_int("PT_LAZY_BATCH", 1);
+        g_pbo_is_device = env_int("PT_PBO_IS_DEVICE", 0);
     }
 
     // pack the frame exactly as the reference wrapper does (raytraceKernel.cu:179-206)
@@ -177,8 +179,17 @@ void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iteratio
     unsigned long long h = fnv1a(pg.data(), pg.size() * sizeof(pt_geom), 1469598103934665603ull);
     h = fnv1a(materials, (size_t)numberOfMaterials * sizeof(material), h);
     h = fnv1a(&cam, sizeof cam, h);
+    const int W = (int)renderCam->resolution.x, H = (int)renderCam->resolution.y;
     if (h != g_scene_hash) {
         flush_pending();
+        // Geometry, materials or camera changed in the middle of a frame: the reference round-trips camera::image on
+        // every call (raytraceKernel.cu:176,215), so the samples rendered so far live on in the host image.  Here they
+        // live on the device until an observation point: bring them home before the device state is rebuilt from it.
+        if (g_scene_hash != 0 && iterations > 1 && g_mode == 0) {
+            int w0 = 0, h0 = 0, own = 0;
+            if (pt_get_resolution(g_ctx, &w0, &h0, &own) == PT_OK && w0 == W && h0 == H)
+                gather_image(reinterpret_cast<float *>(renderCam->image), W, H);
+        }
         for (pt_context *c : g_ctxs) {
             if (pt_upload_scene(c, pg.data(), numberOfGeoms, reinterpret_cast<const pt_material *>(materials),
                                 numberOfMaterials, &cam) != PT_OK) die("pt_upload_scene");
@@ -191,32 +202,25 @@ void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iteratio
     }
 
     const bool final_call = (unsigned)iterations >= renderCam->iterations;
-    const bool observable = PBOpos != NULL || final_call || g_mode == 1 || env_int("PT_SYNC_EVERY_CALL", 0);
-    const int lazy = env_int("PT_LAZY_BATCH", 1);
+    const bool observable = PBOpos != NULL || final_call || g_mode == 1 || g_sync_every_call;
+    const int lazy = g_lazy;
     if (g_pending_count > 0 && g_pending_first + g_pending_count != iterations) flush_pending();   // not consecutive
     if (g_pending_count == 0) g_pending_first = iterations;
     g_pending_count++;
     if (observable || g_pending_count >= lazy) flush_pending();
 
-    const int W = (int)renderCam->resolution.x, H = (int)renderCam->resolution.y;
-    const bool download = final_call || g_mode == 1 || env_int("PT_SYNC_EVERY_CALL", 0);
+    const bool download = final_call || g_mode == 1 || g_sync_every_call;
     if (PBOpos) {
         const float scale = g_mode == 1 ? 1.0f : 1.0f / (float)iterations;
         if (g_ctxs.size() == 1) {
-            if (pt_display(g_ctx, scale, PBOpos, env_int("PT_PBO_IS_DEVICE", 0)) != PT_OK) die("pt_display");
+            if (pt_display(g_ctx, scale, PBOpos, g_pbo_is_device) != PT_OK) die("pt_display");
         } else {
-            // several GPUs: gather, then sendImageToPBO on the host (x255, clamp above only, truncate)
-            if (env_int("PT_PBO_IS_DEVICE", 0)) { fprintf(stderr, "Cuda error: pt_display: PT_PBO_IS_DEVICE needs PT_NGPU=1.\n"); exit(EXIT_FAILURE); }
-            std::vector<float> full((size_t)W * H * 3);
-            memcpy(full.data(), renderCam->image, full.size() * sizeof(float));
-            gather_image(full.data(), W, H);
-            for (size_t i = 0; i < (size_t)W * H; ++i) {
-                float c[3];
-                for (int k = 0; k < 3; ++k) { c[k] = (full[3 * i + k] * scale) * 255.0f; if (c[k] > 255.0f) c[k] = 255.0f; }
-                PBOpos[i].w = 0; PBOpos[i].x = (unsigned char)c[0]; PBOpos[i].y = (unsigned char)c[1]; PBOpos[i].z = (unsigned char)c[2];
-            }
-            if (download) memcpy(renderCam->image, full.data(), full.size() * sizeof(float));
+            // several GPUs: the owned rows travel device to device (peer copies over xGMI) into context 0's
+            // accumulator, which then runs sendImageToPBO like the single-GPU case
+            for (size_t r = 1; r < g_ctxs.size(); ++r)
+                if (pt_gather_rows_peer(g_ctx, g_ctxs[r]) != PT_OK) die("pt_gather_rows_peer");
+            if (pt_display(g_ctx, scale, PBOpos, g_pbo_is_device) != PT_OK) die("pt_display");
         }
     }
-    if (download && !(PBOpos && g_ctxs.size() > 1)) gather_image(reinterpret_cast<float *>(renderCam->image), W, H);
+    if (download) gather_image(reinterpret_cast<float *>(renderCam->image), W, H);
 }

@@ -626,6 +626,8 @@ struct SegArgs {
     uint32_t n_own;                  // GEN: rays of bounce 0 come from the camera, not from the pool
     uint32_t n_rays;                 // = batch * n_own: `batch` consecutive iterations share one launch
     uint32_t batch;                  // ray id = slot * n_own + local; the pool's pixel word is slot<<24 | pixel
+    uint32_t pix_mask;               // 0xFFFFFF while the pixel word carries slot/flag bits; 0xFFFFFFFF for frames above
+                                     //   2^24 pixels (then batch == 1, no direct_light: the word is the raw pixel index)
     float *planes;                   // batch > 1: one accumulator plane per in-flight iteration slot
     size_t plane_stride;             //   (floats); folded into the image in iteration order afterwards
     uint32_t bank;                   // counter bank of this launch group (the host alternates 0/1)
@@ -706,9 +708,9 @@ __global__ __launch_bounds__(kBlock, (NEE || WIDE) ? 4 : PT_SEG_WAVES) void k_bo
                     d = mk((in + 3 * cap)[idx], (in + 4 * cap)[idx], (in + 5 * cap)[idx]);
                     thr = mk((in + 6 * cap)[idx], (in + 7 * cap)[idx], (in + 8 * cap)[idx]);
                     const uint32_t pv = reinterpret_cast<const uint32_t *>(in + 9 * cap)[idx];
-                    slot = NEE ? (pv >> 24) & 0x7Fu : pv >> 24;
+                    slot = NEE ? (pv >> 24) & 0x7Fu : (a.batch > 1u ? pv >> 24 : 0u);
                     flag = pv >> 31;
-                    pixel = pv & 0xFFFFFFu;
+                    pixel = pv & a.pix_mask;
                 }
                 if (NEE) {
                     // every contribution of a path goes to its iteration's plane (folded afterwards)
@@ -825,6 +827,7 @@ __global__ __launch_bounds__(kBlock, PT_SEG_WAVES) void k_bounce_defer(SegArgs a
             if (from_q) {
                 const uint32_t cnt = qcount < 64u ? qcount : 64u;
                 valid = lane < cnt;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 if (valid) {
                     const float *q = ring + ((qhead + lane) & (kQueueCap - 1u));
                     o = mk(q[0 * kQueueCap], q[1 * kQueueCap], q[2 * kQueueCap]);
@@ -886,6 +889,9 @@ __global__ __launch_bounds__(kBlock, PT_SEG_WAVES) void k_bounce_defer(SegArgs a
                         q[10 * kQueueCap] = __uint_as_float(mask);
                     }
                     qcount += (uint32_t)__popcll(cb);
+                    // the ring hands rays from one lane to another: order the stores before any later pop
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
                 }
                 valid = valid && !complex;
             }
@@ -893,7 +899,7 @@ __global__ __launch_bounds__(kBlock, PT_SEG_WAVES) void k_bounce_defer(SegArgs a
             // (B) exact tests on the lane's own candidates: cubes, then spheres, index order, later
             // candidates re-checked against the best hit; ties to the lower index (reference loop order)
             bool alive = false;
-            const uint32_t slot = pv >> 24, pixel = pv & 0xFFFFFFu;
+            const uint32_t slot = a.batch > 1u ? pv >> 24 : 0u, pixel = pv & a.pix_mask;
             if (valid) {
                 float best = 100000000000000000.0f;
                 int hit = -1;
@@ -1046,7 +1052,7 @@ __global__ __launch_bounds__(kBlock, PT_SEG_WAVES) void k_bounce_bin(SegArgs a, 
                     }
                 }
                 if (GEN) mask = valid ? cull_mask(lg, a.G, o, d) : 0u;
-                const uint32_t slot = pv >> 24, pixel = pv & 0xFFFFFFu;
+                const uint32_t slot = a.batch > 1u ? pv >> 24 : 0u, pixel = pv & a.pix_mask;
 
                 bool alive = false;
                 if (valid) {
@@ -1237,7 +1243,7 @@ __global__ __launch_bounds__(kBlock, PT_SEG_WAVES) void k_bounce_bvh(SegArgs a, 
                     pv = reinterpret_cast<const uint32_t *>(in + 9 * cap)[idx];
                 }
             }
-            const uint32_t slot = pv >> 24, pixel = pv & 0xFFFFFFu;
+            const uint32_t slot = a.batch > 1u ? pv >> 24 : 0u, pixel = pv & a.pix_mask;
 
             // (A) per-lane BVH walk -> candidate lists
             const CullRay cr = make_cull_ray(o, d);
@@ -1520,6 +1526,8 @@ struct pt_context {
     bool counts_pending = false;
     uint32_t bank = 0;               // counter bank of the iteration being enqueued (fused segmented path)
     uint32_t batch_max = 1;          // iterations that may share one launch group
+    uint32_t pix_mask = 0xFFFFFFu;   // pixel bits of the pool's pixel word (all 32 for frames above 2^24 pixels)
+    bool empty = false;              // this context owns no row of the frame (row_offset >= H): every call is a no-op
     float *d_planes = nullptr;       // batch_max accumulator planes (W*H*3 floats each)
     bool wide = false;               // 33..256 primitives in LDS: k_bounce_seg<.., WIDE> (mask registers -> packed candidate lists)
     // cfg.streams > 1: this context only owns the frame (image) and fans every call out to `subs`, one
@@ -1551,18 +1559,22 @@ namespace {
 hipEvent_t take_event(pt_context *c) {
     if (!c->free_events.empty()) { hipEvent_t e = c->free_events.back(); c->free_events.pop_back(); return e; }
     hipEvent_t e = nullptr;
-    (void)hipEventCreate(&e);
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;    // the caller then leaves this launch untimed
     return e;
 }
 
 struct Scoped {
     pt_context *c; int kind; hipEvent_t a = nullptr, b = nullptr;
     Scoped(pt_context *ctx, int k) : c(ctx), kind(k) {
-        if (c->cfg.profile) { a = take_event(c); b = take_event(c); (void)hipEventRecord(a, c->stream); }
+        if (c->cfg.profile) {
+            a = take_event(c); b = take_event(c);
+            if (a && b) (void)hipEventRecord(a, c->stream);
+            else { if (a) c->free_events.push_back(a); if (b) c->free_events.push_back(b); a = b = nullptr; }
+        }
     }
     ~Scoped() {
         c->launches[kind]++;
-        if (c->cfg.profile) { (void)hipEventRecord(b, c->stream); c->pending.push_back({a, b, kind}); }
+        if (a && b) { (void)hipEventRecord(b, c->stream); c->pending.push_back({a, b, kind}); }
     }
 };
 
@@ -1848,6 +1860,7 @@ int enqueue_iterations(pt_context *c, uint32_t iteration, uint32_t batch, int st
         a.nseg_in = c->lvl_nseg[b]; a.nseg_out = c->lvl_nseg[b + 1]; a.seg_slots = c->lvl_slots[b];
         a.merge = c->lvl_slots[b + 1] != c->lvl_slots[b] ? 1u : 0u;
         a.bounce = b; a.iteration = iteration; a.n_own = c->n_own; a.cam = c->cam; a.bank = c->bank;
+        a.pix_mask = c->pix_mask;
         a.n_rays = n_rays; a.batch = batch; a.planes = c->d_planes; a.plane_stride = (size_t)c->W * c->H * 3;
         a.bin1_offset = c->nseg + 2u;
         a.lights = c->d_lights; a.nlights = c->nlights;
@@ -1996,7 +2009,12 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     HIPCHK(hipSetDevice(c->cfg.device));
     HIPCHK(hipStreamSynchronize(c->stream));
     const int W = (int)cam->resolution[0], H = (int)cam->resolution[1];
-    if (W < 2 || H < 2 || (int64_t)W * H > (1ll << 30)) { pth::set_error("pt_upload_scene: resolution %dx%d unsupported", W, H); return PT_ERR_ARGUMENT; }
+    // pool indices are 32-bit with headroom for the segment padding: <= 2^28 pixels.  Above 2^24 pixels the pool's
+    // pixel word has no room for the iteration slot / count-emission flag: one iteration per launch, no direct_light.
+    if (W < 2 || H < 2 || (int64_t)W * H > (1ll << 28)) { pth::set_error("pt_upload_scene: resolution %dx%d unsupported (2x2 .. 2^28 pixels)", W, H); return PT_ERR_ARGUMENT; }
+    const bool big_frame = (int64_t)W * H > (1ll << 24);
+    if (big_frame && c->cfg.direct_light != 0 && c->cfg.mode == 0) { pth::set_error("pt_upload_scene: direct_light supports frames up to 2^24 pixels (%dx%d asked)", W, H); return PT_ERR_ARGUMENT; }
+    if (big_frame && c->cfg.compaction == 0 && c->cfg.ordering == 2) { pth::set_error("pt_upload_scene: ordering=2 supports frames up to 2^24 pixels"); return PT_ERR_ARGUMENT; }
     std::vector<GeomRec> g(G);
     std::vector<MatRec> m(M);
     for (int i = 0; i < M; ++i) {
@@ -2018,12 +2036,23 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         world_bounds(geoms[i], &g[i]);
     }
     const int stride = c->cfg.row_stride, offset = c->cfg.row_offset;
-    const int rows = (H - offset + stride - 1) / stride;
+    const int rows = offset < H ? (H - offset + stride - 1) / stride : 0;
     const uint32_t n_own = (uint32_t)rows * (uint32_t)W;
     // Always rebuild the device state: uploads are rare (once per frame), sizes depend on the scene.
     free_scene_buffers(c);
     c->W = W; c->H = H; c->G = G; c->M = M;
     c->n_own = n_own;
+    c->pix_mask = big_frame ? 0xFFFFFFFFu : 0xFFFFFFu;
+    c->empty = (n_own == 0u);
+    if (c->empty) {
+        // a shard without rows (row_offset >= H: more GPUs x streams than rows) is valid and renders nothing
+        HIPCHK(hipMalloc(&c->image_own, (size_t)W * H * 3 * sizeof(float)));
+        HIPCHK(hipMemsetAsync(c->image_own, 0, (size_t)W * H * 3 * sizeof(float), c->stream));
+        if (!c->image) c->image = c->image_own;
+        pth::camera_basis(cam, &c->cfg, &c->cam);
+        c->scene_ready = true;
+        return PT_OK;
+    }
     c->seg_mode = (c->cfg.compaction == 0);
     c->cull = (c->cfg.culling == 0) && c->seg_mode;
     c->defer = c->cull && c->cfg.ordering == 1 && c->cfg.geometry_path == 0 && G <= 32 && c->cfg.mode == 0;
@@ -2142,7 +2171,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         // launches amortise the tail of the static schedule; essential when the frame is sharded over
         // GPUs).  The pool's pixel word keeps the slot in its top 8 bits.
         uint32_t K = 1;
-        if (c->cfg.mode == 0 && (uint64_t)W * H <= (1ull << 24)) {
+        if (c->cfg.mode == 0 && !big_frame) {
             if (c->cfg.batch > 0) K = (uint32_t)c->cfg.batch;
             else K = (uint32_t)((32u * 1024u * 1024u) / n_own);      // 16 at 1080p: measured best (14: +4 %, 18: +8 % time)
             // the slot field has 7 bits beside the count-emission flag; the planes are full frames: <= 4 GiB
@@ -2235,6 +2264,50 @@ int pt_get_image(pt_context *c, float *host_rgb) {
     return check_device_error(c);
 }
 
+int pt_get_rows(pt_context *c, float *host_rgb) {
+    if (!c || !c->scene_ready || !host_rgb) { pth::set_error("pt_get_rows: bad state/argument"); return PT_ERR_STATE; }
+    HIPCHK(hipSetDevice(c->cfg.device));
+    int rc = pt_sync(c);
+    if (rc) return rc;
+    // the rows y = row_offset + k*row_stride of the (shared) full-frame image: one strided 2-D copy
+    const int off = c->cfg.row_offset, stride = c->cfg.row_stride;
+    if (off >= c->H) return PT_OK;
+    const size_t row_bytes = (size_t)c->W * 3 * sizeof(float);
+    const size_t rows = (size_t)(c->H - off + stride - 1) / stride;
+    HIPCHK(hipMemcpy2D(host_rgb + (size_t)off * c->W * 3, row_bytes * stride, c->image + (size_t)off * c->W * 3, row_bytes * stride,
+                       row_bytes, rows, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_gather_rows_peer(pt_context *dst, pt_context *src) {
+    if (!dst || !src || !dst->scene_ready || !src->scene_ready) { pth::set_error("pt_gather_rows_peer: both contexts need a scene"); return PT_ERR_STATE; }
+    if (dst->W != src->W || dst->H != src->H) { pth::set_error("pt_gather_rows_peer: resolutions differ"); return PT_ERR_ARGUMENT; }
+    if (dst == src || dst->image == src->image) return PT_OK;
+    int rc = pt_sync(src);
+    if (rc) return rc;
+    rc = pt_sync(dst);
+    if (rc) return rc;
+    const int off = src->cfg.row_offset, stride = src->cfg.row_stride;
+    if (off >= src->H) return PT_OK;
+    const size_t row_bytes = (size_t)src->W * 3 * sizeof(float);
+    const size_t rows = (size_t)(src->H - off + stride - 1) / stride;
+    HIPCHK(hipSetDevice(dst->cfg.device));
+    if (dst->cfg.device != src->cfg.device) {
+        int can = 0;
+        HIPCHK(hipDeviceCanAccessPeer(&can, dst->cfg.device, src->cfg.device));
+        if (can) {
+            hipError_t e = hipDeviceEnablePeerAccess(src->cfg.device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { pth::set_error("hipDeviceEnablePeerAccess failed: %s", hipGetErrorString(e)); return PT_ERR_HIP; }
+            (void)hipGetLastError();
+        }
+    }
+    // unified addressing: hipMemcpyDefault routes a cross-device copy over the peer link (xGMI)
+    HIPCHK(hipMemcpy2DAsync(dst->image + (size_t)off * dst->W * 3, row_bytes * stride, src->image + (size_t)off * src->W * 3, row_bytes * stride,
+                            row_bytes, rows, hipMemcpyDefault, dst->stream));
+    HIPCHK(hipStreamSynchronize(dst->stream));
+    return PT_OK;
+}
+
 int pt_render(pt_context *c, int first_iteration, int count) {
     if (!c || !c->scene_ready) { pth::set_error("pt_render: no scene uploaded"); return PT_ERR_STATE; }
     if (first_iteration < 1 || count < 0) { pth::set_error("pt_render: iterations are 1-based"); return PT_ERR_ARGUMENT; }
@@ -2243,6 +2316,7 @@ int pt_render(pt_context *c, int first_iteration, int count) {
         for (pt_context *s : c->subs) { int rc = pt_render(s, first_iteration, count); if (rc) return rc; }
         return PT_OK;
     }
+    if (c->empty) { c->iterations += (uint64_t)count; return PT_OK; }
     for (int it = first_iteration; it < first_iteration + count; ++it) {
         if (c->cfg.mode == 1) {
             Scoped s(c, 1);
@@ -2284,6 +2358,7 @@ int pt_display(pt_context *c, float scale, void *out, int out_is_device) {
         return pt_display(c->subs[0], scale, out, out_is_device);
     }
     const uint32_t n = (uint32_t)c->W * c->H;
+    if (!c->d_display && !out_is_device) HIPCHK(hipMalloc(&c->d_display, (size_t)n * sizeof(uchar4)));
     uchar4 *dst = out_is_device ? static_cast<uchar4 *>(out) : c->d_display;
     {
         Scoped s(c, 2);
@@ -2370,6 +2445,7 @@ int pt_get_resolution(pt_context *c, int *w, int *h, int *owned) {
 int pt_debug_primary_hits(pt_context *c, float *dir, int *hit, float *t, float *P, float *N) {
     if (!c || !c->scene_ready) { pth::set_error("pt_debug_primary_hits: no scene uploaded"); return PT_ERR_STATE; }
     if (!c->subs.empty()) { pth::set_error("pt_debug_primary_hits: parity hooks need streams = 1"); return PT_ERR_STATE; }
+    if (c->empty) { pth::set_error("pt_debug_primary_hits: this context owns no rows"); return PT_ERR_STATE; }
     HIPCHK(hipSetDevice(c->cfg.device));
     const size_t n = (size_t)c->W * c->H;
     float *d_dir = nullptr, *d_t = nullptr, *d_P = nullptr, *d_N = nullptr;
@@ -2399,6 +2475,7 @@ int pt_debug_trace_pool(pt_context *c, int iteration, int bounces, int *count, f
     if (!c || !c->scene_ready || c->cfg.mode != 0) { pth::set_error("pt_debug_trace_pool: needs a path-trace context with a scene"); return PT_ERR_STATE; }
     if (!c->subs.empty()) { pth::set_error("pt_debug_trace_pool: parity hooks need streams = 1"); return PT_ERR_STATE; }
     if (bounces < 0 || bounces > c->cfg.max_depth || iteration < 1) { pth::set_error("pt_debug_trace_pool: bad bounces/iteration"); return PT_ERR_ARGUMENT; }
+    if (c->empty) { if (count) *count = 0; return PT_OK; }
     HIPCHK(hipSetDevice(c->cfg.device));
     // render into a scratch accumulator and restore the counters afterwards: the hook leaves image
     // and statistics untouched

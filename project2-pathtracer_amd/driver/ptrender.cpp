@@ -156,16 +156,13 @@ int main(int argc, char **argv) {
         const int first = 1, count = iterations;
         for (pt_context *c : ctxs)                                                 // asynchronous on every device
             if (pt_render(c, first, count) != PT_OK) die("pt_render");
-        std::vector<float> image((size_t)W * H * 3), tmp;
+        std::vector<float> image((size_t)W * H * 3);
         if (ctxs.size() == 1) {
             if (pt_get_image(ctxs[0], image.data()) != PT_OK) die("Kernel failed!");
         } else {
-            tmp.resize(image.size());
-            for (size_t r = 0; r < ctxs.size(); ++r) {
-                if (pt_get_image(ctxs[r], tmp.data()) != PT_OK) die("Kernel failed!");
-                for (int y = (int)r; y < H; y += (int)ctxs.size())
-                    memcpy(&image[(size_t)y * W * 3], &tmp[(size_t)y * W * 3], (size_t)W * 3 * sizeof(float));
-            }
+            // every GPU sends only the rows it owns (1/N of the frame over its own PCIe link)
+            for (pt_context *c : ctxs)
+                if (pt_get_rows(c, image.data()) != PT_OK) die("Kernel failed!");
         }
         std::string filename = pt_scene_image_name(scene);
         const std::string n = std::to_string(frame);

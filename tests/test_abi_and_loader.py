@@ -28,7 +28,8 @@ def test_library_exports_every_declared_symbol(pkg):
     for name in declared:
         assert hasattr(L, name), "libptmi355.so does not export %s" % name
     assert sorted(pkg.EXPORTS) == declared
-    assert pkg.lib().pt_abi_version() == 2
+    version = int(re.search(r"#define\s+PTMI355_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert pkg.lib().pt_abi_version() == version == 3
 
 
 def test_pod_sizes_match_reference_structs(pkg):

@@ -1,0 +1,108 @@
+"""-m gpu: round-2 additions -- frames above 2^24 pixels, empty shards, the owned-row exchange
+(pt_get_rows / pt_gather_rows_peer) and the headline launch variant checked against the oracle at
+full size.  Same bar as tests/test_gpu_parity.py: bit-exact (numpy == on float32)."""
+import numpy as np
+import pytest
+
+import orc
+from gpu_common import make_tracer, oracle_config, to_product
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("ordering", [0, 1])
+def test_frame_above_2pow24_pixels_matches_oracle_rows(pt, ordering):
+    """4100x4100 = 16.8 Mpx: the pool's pixel word has no room for an iteration slot any more; the
+    library renders one iteration per launch with the raw 32-bit pixel index."""
+    sc = orc.load_golden_scene("cornell_mirror").with_resolution(4100, 4100)
+    tr = make_tracer(sc, depth=4, ordering=ordering)
+    tr.set_image(None)
+    tr.render(1, 2)
+    got = tr.image()
+    st = tr.stats()
+    assert st.live[0] == 2 * 4100 * 4100 and all(st.live[k] >= st.live[k + 1] for k in range(4))
+    stride, off = 1025, 1019                       # rows 1019, 2044, 3069, 4094: far beyond pixel 2^24
+    want, _ = orc.render(sc, oracle_config(4, row_offset=off, row_stride=stride), 1, 2)
+    rows = np.arange(4100) % stride == off
+    assert rows.sum() == 4 and want[rows].any()
+    assert np.array_equal(got[rows], want[rows])
+    tr.close()
+
+
+def test_resolution_limits_are_refused_not_truncated(pt):
+    sc = orc.load_golden_scene("cornell_mirror").with_resolution(4100, 4100)
+    with pytest.raises(pt.PtError, match="direct_light"):
+        make_tracer(sc, depth=4, direct_light=1)
+    huge = orc.load_golden_scene("cornell_mirror").with_resolution(32768, 8193)     # > 2^28 pixels
+    with pytest.raises(pt.PtError, match="unsupported"):
+        make_tracer(huge, depth=4)
+
+
+def test_shards_without_rows_are_valid_and_empty(pt):
+    """More shards than rows: row_offset >= H owns nothing; rendering is a no-op and the
+    remaining shards still add up to the full frame.  Also through streams > rows."""
+    sc = orc.load_golden_scene("sampleScene").with_resolution(64, 5)
+    want, live = orc.render(sc, oracle_config(6), 1, 3)
+    total = np.zeros_like(want)
+    for r in range(8):
+        tr = make_tracer(sc, depth=6, row_offset=r, row_stride=8)
+        tr.set_image(None)
+        tr.render(1, 3)
+        img = tr.image()
+        if r >= 5:
+            assert tr.owned == 0 and not img.any()
+        total += img
+        tr.close()
+    assert np.array_equal(total, want)
+    tr = make_tracer(sc, depth=6, streams=8)
+    tr.set_image(None)
+    tr.render(1, 3)
+    st = tr.stats()
+    assert np.array_equal(tr.image(), want)
+    assert [st.live[k] for k in range(7)] == [int(v) for v in live]
+    tr.close()
+
+
+@pytest.mark.parametrize("streams", [1, 2])
+def test_owned_row_exchange_host_and_peer(pt, streams):
+    """The per-frame exchange of a row-sharded render: pt_get_rows moves only the owned rows to the host,
+    pt_gather_rows_peer moves them device to device into another context's accumulator."""
+    sc = orc.load_golden_scene("cornell_mirror").with_resolution(160, 91)
+    want, _ = orc.render(sc, oracle_config(5), 1, 3)
+    N = 3
+    trs = [make_tracer(sc, depth=5, row_offset=r, row_stride=N, streams=streams) for r in range(N)]
+    for tr in trs:
+        tr.set_image(None)
+        tr.render(1, 3)
+    host = np.full((91, 160, 3), -7.0, np.float32)
+    for r, tr in enumerate(trs):
+        tr.get_rows(host)
+        seen = np.arange(91) % N <= r
+        assert np.array_equal(host[seen], want[seen]) and (host[~seen] == -7.0).all()
+    assert np.array_equal(host, want)
+    for tr in trs[1:]:
+        trs[0].gather_rows_from(tr)
+    assert np.array_equal(trs[0].image(), want)
+    for tr in trs:
+        tr.close()
+
+
+@pytest.mark.parametrize("kw", [dict(ordering=1, streams=2), dict(ordering=0, streams=2), dict(ordering=1, streams=1),
+                                dict(direct_light=1, streams=2)])
+def test_headline_launch_variant_full_size_against_oracle_rows(pt, kw):
+    """What bench.py times (configs[2] at 1920x1080, ordering=1, streams=2, automatic batching over a
+    20-iteration launch group) against the oracle on an interleave of rows."""
+    sc = orc.load_golden_scene("cornell_mirror")
+    assert (sc.W, sc.H) == (1920, 1080)
+    tr = make_tracer(sc, depth=8, **kw)
+    tr.set_image(None)
+    tr.render(1, 20)
+    got = tr.image()
+    st = tr.stats()
+    okw = dict(direct_light=1) if kw.get("direct_light") else {}
+    want, _ = orc.render(sc, oracle_config(8, row_offset=77, row_stride=216, **okw), 1, 20)
+    rows = np.arange(1080) % 216 == 77
+    assert rows.sum() == 5
+    assert np.array_equal(got[rows], want[rows])
+    assert st.live[0] == 20 * 1920 * 1080
+    tr.close()
