@@ -193,13 +193,17 @@ static inline v3 mulmv(const float m[16], v3 v, float w) {
  * build, where `min(t1,t2)`/`max(t1,t2)` resolved to HIP's host-side int overloads and
  * truncated the roots -- used ONLY by tests/test_oracle_kats.py to explain the three sphere
  * rows of SURVEY.md section 8c (t_obj there is exactly floor(near root)). */
-static float sphere_test_impl(const orc_geom *g, int int_minmax, const float o[3], const float d[3],
+static float sphere_test_impl(const orc_geom *g, int variant, const float o[3], const float d[3],
                               float P[3], float N[3]) {
+    const int int_minmax = variant & 1, pow_double = variant & 2;
     const float radius = .5f;
     v3 ro = mulmv(g->inverseTransform, vload(o), 1.0f);
     v3 rd = vnormalize(mulmv(g->inverseTransform, vload(d), 0.0f));
     float vDotDirection = vdot(ro, rd);
     float radicand = vDotDirection * vDotDirection - (vdot(ro, ro) - (radius * radius));
+    /* pow_double (tests only): C++11's pow(float,int) returns double, so a present-day host build of the
+     * reference evaluates the two subtractions in double and rounds once (oracle/ref_kernels_probe.cpp) */
+    if (pow_double) radicand = (float)((double)(vDotDirection * vDotDirection) - ((double)vdot(ro, ro) - 0.25));
     if (radicand < 0.0f) return -1.0f;
     float squareRoot = sqrtf(radicand);
     float firstTerm = -vDotDirection;
@@ -225,6 +229,16 @@ float orc_sphere_test(const orc_geom *g, const float o[3], const float d[3], flo
 
 float orc_sphere_test_intminmax(const orc_geom *g, const float o[3], const float d[3], float P[3], float N[3]) {
     return sphere_test_impl(g, 1, o, d, P, N);
+}
+
+float orc_sphere_test_powdouble(const orc_geom *g, const float o[3], const float d[3], float P[3], float N[3]) {
+    return sphere_test_impl(g, 2, o, d, P, N);
+}
+
+/* getPointOnRay (src/intersections.h:46-48): origin + float(t - .0001) * normalize(direction) */
+void orc_point_on_ray(const float o[3], const float d[3], float t, float out[3]) {
+    float tt = (float)((double)t - .0001);
+    vstore(out, vadd(vload(o), vscale(vnormalize(vload(d)), tt)));
 }
 
 /* src/intersections.h:73-164 (unit cube [-.5,.5]^3).  inside_hits = 0 is the reference

@@ -129,6 +129,10 @@ void  orc_camera_ray(const orc_camera_basis *b, const orc_config *cfg, int x, in
 void  orc_multiply_mv(const float m[16], const float v[4], float out[3]);
 float orc_sphere_test(const orc_geom *g, const float o[3], const float d[3], float P[3], float N[3]);
 float orc_sphere_test_intminmax(const orc_geom *g, const float o[3], const float d[3], float P[3], float N[3]);
+/* tests only: `pow(radius,2)` as the C++11 double overload (what oracle/_ref/ref_kernels_probe is built with) */
+float orc_sphere_test_powdouble(const orc_geom *g, const float o[3], const float d[3], float P[3], float N[3]);
+/* getPointOnRay, src/intersections.h:46-48 */
+void orc_point_on_ray(const float o[3], const float d[3], float t, float out[3]);
 float orc_box_test(const orc_geom *g, int inside_hits, const float o[3], const float d[3],
                    float P[3], float N[3]);
 int   orc_nearest_hit(const orc_geom *geoms, int ngeoms, const orc_material *mats,

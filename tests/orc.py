@@ -74,6 +74,9 @@ def lib():
                                  C.c_float, C.c_float, C.c_float, C.c_float, f3, f3]
     L.orc_sphere_test.restype = C.c_float; L.orc_sphere_test.argtypes = [C.POINTER(Geom), f3, f3, f3, f3]
     L.orc_sphere_test_intminmax.restype = C.c_float; L.orc_sphere_test_intminmax.argtypes = [C.POINTER(Geom), f3, f3, f3, f3]
+    L.orc_sphere_test_powdouble.restype = C.c_float; L.orc_sphere_test_powdouble.argtypes = [C.POINTER(Geom), f3, f3, f3, f3]
+    L.orc_point_on_ray.restype = None; L.orc_point_on_ray.argtypes = [f3, f3, C.c_float, f3]
+    L.orc_multiply_mv.restype = None; L.orc_multiply_mv.argtypes = [f3, f3, f3]
     L.orc_box_test.restype = C.c_float; L.orc_box_test.argtypes = [C.POINTER(Geom), C.c_int, f3, f3, f3, f3]
     L.orc_nearest_hit.restype = C.c_int
     L.orc_nearest_hit.argtypes = [C.POINTER(Geom), C.c_int, C.POINTER(Material), f3, f3, f3, f3, f3]
