@@ -2,7 +2,9 @@
 """bench.py -- Mray/s of the MI355X path tracer on BASELINE.json's headline configuration.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+  (N > 1: either pre-launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`,
+   or started plainly -- then this process spawns exactly that command as a child BEFORE touching the GPU and
+   relays rank 0's JSON line and the exit code)
 
 A "step" is ONE render iteration of the workload: one camera ray per pixel of the frame traced
 for `depth` bounces through generate -> (trace + scatter + accumulate + compact)* on the GPU(s).
@@ -73,6 +75,16 @@ def gather_rows_to_root(tensor, H, W, dst=0):
             if r != dst:
                 frame[r::world] = recv[r][:len(range(r, H, world))]
     return tensor
+
+
+def kernel_source_id():
+    """sha256[:16] of the kernel sources: ties borrowed counter figures (profiles/traffic_latest.json) to a build"""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("pt_kernels.hip", "pt_device.hpp"):
+        with open(os.path.join(ROOT, "project2-pathtracer_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def algorithmic_bytes(stats, depth, fused_generate=True):
@@ -185,7 +197,24 @@ def main():
                     help="contexts per GPU, each on its own HIP stream and owning every (streams*gpus)-th row: the tails of one "
                          "context's launches are filled by the other's (bit-identical, like the multi-GPU sharding); 1 = off")
     ap.add_argument("--direct-light", type=int, default=0, help="1 = next-event estimation (one shadow ray per diffuse hit); not the headline configuration")
+    ap.add_argument("--repeats", type=int, default=7, help="the exact K-step timed pass is repeated this many times; value = the median pass")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # not launched by torchrun: start the N ranks as a CHILD (nothing in this process has touched the GPU, and
+        # nothing is exec'ed over a process that has); relay the child's output and exit code
+        import socket
+        import subprocess
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        child = subprocess.run(cmd, env=env)
+        raise SystemExit(child.returncode)
 
     import torch
     import torch.distributed as dist
@@ -194,9 +223,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
-        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d (start it plainly, or with torch.distributed.run --nproc-per-node %d)"
+                         % (world, args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the path tracer has no CPU fallback")
     backend = os.environ.get("PT_BENCH_BACKEND", "nccl")
@@ -273,38 +301,45 @@ def main():
             dt = float(t.item())
         return dt
 
-    # 1) the metric: K steps with nothing but the render launches on the stream
-    elapsed = timed_pass(args.warmup + 1, False)
-    # 2) the same K steps again with every launch bracketed by HIP events on the render stream
-    #    (per-kernel durations for the roofline; the events cost a few % so they stay out of `value`)
+    # 0) one untimed pass of the SAME K-step shape (the W warm-up steps above form a differently sized launch group)
+    timed_pass(args.warmup + 1, False)
+    # 1) the metric: the exact K-step pass, repeated; `value` is the MEDIAN pass (min / max reported beside it)
+    R = max(1, args.repeats)
+    passes = [timed_pass(args.warmup + 1, False) for _ in range(R)]
+    order = sorted(range(R), key=lambda k: passes[k])
+    elapsed = passes[order[R // 2]] if R % 2 else 0.5 * (passes[order[R // 2 - 1]] + passes[order[R // 2]])
+    raw = tracer.stats()                          # counters of the last pass: every pass renders the same iterations
+    # 2) the same K steps once more with every launch bracketed by HIP events on the render stream: per-launch
+    #    durations (what rocprofv3 --kernel-trace reports).  NOT used for `value` or `roofline.frac`.
     elapsed_events = None
+    ev = None
     if not args.no_kernel_events:
         elapsed_events = timed_pass(args.warmup + 1, True)
-
-    raw = tracer.stats()
+        ev = tracer.stats()
     import types
     stats = types.SimpleNamespace(live=[int(raw.live[k]) for k in range(65)], emitted=int(raw.emitted), iterations=int(raw.iterations),
-                                  bounce_launches=int(raw.bounce_launches), bounce_ms=float(raw.bounce_ms))
-    # one stream: bounce_ms = the summed HIP-event durations of the bounce launches.  Several streams: the library
-    # reports the longest stream's sum (the launches overlap); every stream's sum spans about the same interval
-    stats.bounce_ms_sum = stats.bounce_ms * S
-    if S > 1 and elapsed_events:
-        stats.bounce_ms = elapsed_events * 1e3       # rank 0's pass incl. fold and launch gaps (>= the union of the kernel intervals)
+                                  bounce_launches=int(raw.bounce_launches))
     nbytes, design_bytes, live = algorithmic_bytes(stats, depth, fused_generate=(args.compaction == 0))
     result = None
     if rank == 0:
         value = W * H * args.steps * depth / elapsed / 1e6
-        roof = None
-        if stats.bounce_ms > 0 and stats.bounce_launches:
-            launches = int(stats.bounce_launches)
-            avg_ms = stats.bounce_ms_sum / launches          # durations as rocprofv3 sees them (streams overlap)
-            achieved = nbytes / (stats.bounce_ms * 1e-3) / 1e9
-            traffic = None
-            valu = None
-            tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-            if world == 1 and os.path.exists(tpath):
-                try:
-                    rec = json.load(open(tpath)).get(args.workload, {})
+        launches = max(1, int(stats.bounce_launches))
+        # roofline on the SAME pass as `value`: SURVEY.md 8(d)'s algorithmic bytes of the K steps / that pass's wall time
+        achieved = nbytes / elapsed / 1e9
+        traffic = None
+        valu = None
+        provenance = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if world == 1 and os.path.exists(tpath):
+            try:
+                rec = json.load(open(tpath)).get(args.workload, {})
+                current = kernel_source_id()
+                stale = rec.get("kernel_source_id") != current
+                provenance = {"file": "profiles/traffic_latest.json", "profile": rec.get("profile"), "steps_profiled": rec.get("steps_profiled"),
+                              "kernel_source_id": rec.get("kernel_source_id"), "current_kernel_source_id": current, "stale": stale,
+                              "note": "counter figures come from a SEPARATE rocprofv3 --pmc run of this command (tools/profile.sh), scaled per step; "
+                                      "they are dropped (null) when the kernels have changed since that run"}
+                if not stale:
                     per_step = rec.get("hbm_bytes_per_step")
                     traffic = round(per_step * args.steps / launches) if per_step else None
                     vi = rec.get("valu_wave_instructions_per_step")
@@ -312,37 +347,53 @@ def main():
                         # secondary bound: wave64 VALU issue.  The non-packed f32 rate behind the
                         # guide's 78.6 TFLOP/s is one wave64 instruction per 4 cycles per SIMD (16 lanes/clk);
                         # plain mul/add/mov issue in ~2 cycles (tools/ubench/pk_rate.hip), the hard ceiling.
-                        rate = vi * args.steps / (stats.bounce_ms * 1e-3)
+                        rate = vi * args.steps / elapsed
                         valu = {"wave_instructions_per_step": vi, "achieved_G_wave_inst_per_s": round(rate / 1e9, 1),
                                 "peak_G_wave_inst_per_s": 1228.8, "frac": round(rate / 1.2288e12, 4),
                                 "frac_of_4_cycle_issue": round(rate / 0.6144e12, 4),
-                                "note": "instruction count from rocprofv3 SQ_INSTS_VALU (profiles/), duration live; peak = 1024 SIMDs x 2.4 GHz / 2 cycles, "
+                                "wave_instructions_per_64_live_ray_bounces": round(vi / max(1.0, sum(live[:depth]) / max(1, stats.iterations) / 64.0), 1),
+                                "note": "instruction count from rocprofv3 SQ_INSTS_VALU (see traffic_source), duration = the value pass; peak = 1024 SIMDs x 2.4 GHz / 2 cycles, "
                                         "frac_of_4_cycle_issue = against one wave64 instruction per 4 cycles per SIMD (the non-packed f32 rate)"}
-                except Exception:
-                    traffic = None
-            roof = {"bound": "hbm", "kernel": "k_bounce_defer / k_bounce_seg (cull + exact tests + scatter + accumulate + segmented compaction; bounce 0 also generates)",
-                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": round(nbytes / launches), "avg_launch_us": round(avg_ms * 1e3, 2),
-                    "duration": ("sum of the HIP-event durations of the bounce launches" if S == 1 else
-                                 "wall time of the event-bracketed pass (streams overlap; includes k_fold and launch gaps)"),
-                    "bytes_formula": "SURVEY.md 8(d): N0*40 + sum_k[N_k*40 + N_k+1*40 + (N_k-N_k+1)*24], from the device live-ray counters",
-                    "design_moved": {"bytes_per_launch": round(design_bytes / launches),
-                                     "achieved": round(design_bytes / (stats.bounce_ms * 1e-3) / 1e9, 1),
-                                     "frac": round(design_bytes / (stats.bounce_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                     "note": "bytes this implementation actually has to move (fused generation, no write-back at the last bounce, accumulator touched by emitter hits only)"},
-                    "launches": launches, "rank0_share_of_frame": round(1.0 / world, 4), "valu_issue": valu}
+            except Exception:
+                traffic = None
+        kernel_events = None
+        if ev is not None and int(ev.bounce_launches):
+            # one stream: bounce_ms = the summed HIP-event durations.  Several streams: the library reports the longest
+            # stream's sum (the launches overlap); every stream's sum spans about the same interval
+            kernel_events = {"avg_launch_us": round(float(ev.bounce_ms) * S / int(ev.bounce_launches) * 1e3, 2),
+                             "busiest_stream_bounce_ms_per_step": round(float(ev.bounce_ms) / args.steps, 4),
+                             "ms_per_step_with_kernel_events": round(elapsed_events / args.steps * 1e3, 4),
+                             "kernel_only_frac": round(nbytes / (float(ev.bounce_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "note": "from one extra pass with HIP events around every launch on the render streams (slower than the value pass); "
+                                     "kernel_only_frac = algorithmic bytes / the busiest stream's summed bounce-kernel time / 8 TB/s"}
+        roof = {"bound": "hbm", "kernel": "k_bounce_* (cull + exact tests + scatter + accumulate + segmented compaction; bounce 0 also generates)",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": provenance,
+                "algorithmic_bytes_per_step": round(nbytes / args.steps), "algorithmic_bytes_per_launch": round(nbytes / launches),
+                "duration": "wall time of the median K-step pass = the pass `value` and `ms_per_step` come from (launch gaps and k_fold included): "
+                            "frac = algorithmic_bytes_per_step / ms_per_step / 8e12",
+                "bytes_formula": "SURVEY.md 8(d): N0*40 + sum_k[N_k*40 + N_k+1*40 + (N_k-N_k+1)*24], from the device live-ray counters",
+                "design_moved": {"bytes_per_step": round(design_bytes / args.steps),
+                                 "achieved": round(design_bytes / elapsed / 1e9, 1),
+                                 "frac": round(design_bytes / elapsed / 1e9 / HBM_PEAK_GBS, 4),
+                                 "note": "bytes this implementation actually has to move (fused generation, no write-back at the last bounce, accumulator touched by emitter hits only)"},
+                "launches": launches, "rank0_share_of_frame": round(1.0 / world, 4), "kernel_events": kernel_events, "valu_issue": valu}
+        live_per_step = sum(live[:depth]) / max(1, int(stats.iterations))
         result = {
             "metric": "Mray/s (rays launched x bounces / s) at 1080p, 8 bounces" if args.workload in ("c3", "c4") else "Mray/s (rays launched x bounces / s)",
             "value": round(value, 1), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "repeats": R, "value_is": "median of %d identical K-step passes" % R,
+            "value_min": round(W * H * args.steps * depth / max(passes) / 1e6, 1), "value_max": round(W * H * args.steps * depth / min(passes) / 1e6, 1),
+            "spread": round((max(passes) - min(passes)) / elapsed, 4),
+            "live_Mray_bounces_per_s": round(live_per_step * args.steps / elapsed / 1e6, 1),
             "config": {"workload": desc, "scene": scene_path, "resolution": [W, H], "bounces": depth,
                        "rays_per_step": W * H, "sharding": "rows interleaved over %d GPU(s), 1 RCCL %s per frame" % (world, "gather of the owned rows" if args.exchange == "gather" else "reduce"),
-                       "live_ray_bounces_per_step": round(sum(live[:depth]) / max(1, int(stats.iterations))),
+                       "live_ray_bounces_per_step": round(live_per_step),
                        "compaction": ("segmented, wave-autonomous; " + {0: "stable order (ordering=0)", 1: "sparse-work queue (ordering=1)", 2: "binned two-ended (ordering=2)"}[args.ordering]) if args.compaction == 0 else "global look-back scan",
                        "direct_light": bool(args.direct_light), "streams_per_gpu": S,
-                       "ms_per_step_with_kernel_events": round(elapsed_events / args.steps * 1e3, 4) if elapsed_events else None},
+                       "warmup_passes": "W steps + one untimed K-step pass (same launch-group shape as the timed passes)"},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

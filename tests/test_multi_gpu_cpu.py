@@ -35,8 +35,20 @@ def test_row_sharded_exchange_is_bit_identical(tmp_path, world, exchange):
     assert out.read_text() == "OK", logs
 
 
-def test_bench_rejects_mismatched_world_size():
+def test_bench_launches_its_own_ranks_and_rejects_a_mismatched_world():
+    """`python bench.py --gpus N` started plainly (no RANK in the environment) spawns the N ranks itself as a child
+    `torch.distributed.run` and relays the exit code.  Without a GPU every rank must stop with the no-CPU-fallback
+    message -- which here proves that N ranks were started.  A pre-launched world of the wrong size is refused."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["PT_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    text = r.stderr + r.stdout
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0
+        assert text.count("bench.py needs a GPU") >= 2, text[-3000:]
     env = dict(os.environ, WORLD_SIZE="1", RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=120)
-    assert r.returncode != 0 and "torch.distributed.run" in (r.stderr + r.stdout)
+    assert r.returncode != 0 and "does not match --gpus" in (r.stderr + r.stdout)

@@ -8,9 +8,9 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-# 64 timed + 32 warm-up steps = three FULL launch groups per context (2 contexts x 32 iterations at 1080p), so the
-# per-kernel averages are comparable with the default bench run (200 steps = six full groups + a short one)
-BENCH="python3 $ROOT/bench.py --steps 64 --warmup 32 --no-cpu-baseline --no-kernel-events $*"
+# 32 warm-up steps + 2 passes (one untimed, one timed: --repeats 1) of 64 steps = 160 rendered steps in FULL launch
+# groups (2 contexts x 32 iterations at 1080p), so the per-kernel averages are comparable with the default bench run
+BENCH="python3 $ROOT/bench.py --steps 64 --warmup 32 --repeats 1 --no-cpu-baseline --no-kernel-events $*"
 cd /tmp
 echo "== kernel trace"; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- $BENCH > "$OUT/kt.log" 2>&1 || { echo "kernel trace failed"; tail -5 "$OUT/kt.log"; exit 1; }
 [ -n "${KT_ONLY:-}" ] && { echo "kernel trace only"; exit 0; }

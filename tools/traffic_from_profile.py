@@ -7,6 +7,8 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import kernel_source_id  # noqa: E402
 tag, steps = sys.argv[1], int(sys.argv[2])
 workload = sys.argv[3] if len(sys.argv) > 3 else "c3"
 d = json.load(open(os.path.join(ROOT, "profiles", tag + "_summary.json")))
@@ -24,7 +26,7 @@ rec = json.load(open(path)) if os.path.exists(path) else {}
 rec[workload] = {
     "hbm_bytes_per_step": round((2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 / steps),
     "hbm_bytes_per_step_uncorrected": round((tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 / steps),
-    "steps_profiled": steps, "dispatches": dispatches,
+    "steps_profiled": steps, "dispatches": dispatches, "profile": tag, "kernel_source_id": kernel_source_id(),
     "valu_wave_instructions_per_step": round(tot["SQ_INSTS_VALU"] / steps),
     "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of the bench.py command in tools/profile.sh (%s, bench "
            "defaults); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch (gfx950 FETCH_SIZE counts 64 B per 128-B request on wide "
