@@ -185,7 +185,7 @@ def main():
     ap.add_argument("--chunk-rays", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--merge-floor", type=int, default=0)
-    ap.add_argument("--ordering", type=int, default=1, help="0 = stable compaction (library default), 1 = sparse-work queue, 2 = binned two-ended compaction")
+    ap.add_argument("--ordering", type=int, default=1, help="0 = stable compaction (library default), 1 = typed work queues, 2 = binned two-ended compaction, 3 = round 1 sparse-work queue")
     ap.add_argument("--bvh", type=int, default=0, help="experimental: 1 = per-lane BVH walk, 2 = uniform scan into candidate lists (0 = block-wise culling)")
     ap.add_argument("--batch", type=int, default=0, help="iterations per launch group (0 = auto, 1 = off)")
     ap.add_argument("--resolution", default="", help="WxH override of the scene RES line (experiments only)")
@@ -391,7 +391,7 @@ def main():
             "config": {"workload": desc, "scene": scene_path, "resolution": [W, H], "bounces": depth,
                        "rays_per_step": W * H, "sharding": "rows interleaved over %d GPU(s), 1 RCCL %s per frame" % (world, "gather of the owned rows" if args.exchange == "gather" else "reduce"),
                        "live_ray_bounces_per_step": round(live_per_step),
-                       "compaction": ("segmented, wave-autonomous; " + {0: "stable order (ordering=0)", 1: "sparse-work queue (ordering=1)", 2: "binned two-ended (ordering=2)"}[args.ordering]) if args.compaction == 0 else "global look-back scan",
+                       "compaction": ("segmented, wave-autonomous; " + {0: "stable order (ordering=0)", 1: "typed work queues (ordering=1)", 2: "binned two-ended (ordering=2)", 3: "round-1 sparse-work queue (ordering=3)"}[args.ordering]) if args.compaction == 0 else "global look-back scan",
                        "direct_light": bool(args.direct_light), "streams_per_gpu": S,
                        "warmup_passes": "W steps + one untimed K-step pass (same launch-group shape as the timed passes)"},
             "roofline": roof,

@@ -106,12 +106,16 @@ typedef struct {
                                 are identical: each in-flight iteration accumulates into its own plane
                                 and the planes are folded into the image in iteration order. */
     int   ordering;          /* 0 = stable: the compacted stream keeps generation order (default)
-                                1 = sparse-work queue: rays with non-trivial candidate sets are gathered
-                                    into dense wave groups inside their segment (faster; survivors keep
-                                    their segment but not their order inside it; results identical)
+                                1 = typed work queues (<= 32 primitives, LDS tables): the unit of work is one exact
+                                    test of a ray against its nearest untested candidate; rays wait on wave-private
+                                    LDS stacks by candidate type and every stage runs on full waves; survivors fill
+                                    the wave's own segments densely (fastest; survivors keep their wave, not their
+                                    segment or order; results identical)
                                 2 = binned: every scattered ray is classified by the culling pass of its NEW
                                     direction and written to the front (trivial candidate set) or the back of
-                                    its segment; the candidate mask travels with the ray */
+                                    its segment; the candidate mask travels with the ray
+                                3 = round 1's sparse-work queue: only rays with non-trivial candidate sets are
+                                    regrouped (kept for comparison) */
     int   bvh;               /* experimental culling structures for <= 256 primitives (both bit-identical, both
                                 measured SLOWER than the default block-wise culling at 256 primitives, see
                                 DESIGN.md): 1 = per-lane BVH walk (LDS nodes, per-lane stack and candidate

@@ -78,9 +78,9 @@ float orc_u01(uint32_t x) {
 
 /* Build-defined integer stream seed: one independent minstd stream per
  * (global pixel index, 1-based iteration, stream id); stream 0 = camera sample,
- * stream 1+b = scatter at bounce b. */
+ * stream 1+b = scatter at bounce b.  One hash (a bijection on 32 bits) of an injective mix. */
 uint32_t orc_stream_seed(uint32_t pixel, uint32_t iteration, uint32_t stream) {
-    return orc_hash(orc_hash(pixel) + 0x9E3779B9u * iteration + stream);
+    return orc_hash(pixel + 0x9E3779B9u * iteration + 0x85EBCA6Bu * stream);
 }
 
 /* src/raytraceKernel.cu:30-37: seed = hash(index*time) with index int, time float, i.e. a

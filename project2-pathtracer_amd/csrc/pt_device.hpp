@@ -13,6 +13,11 @@
 
 #include "pt_camrec.hpp"
 
+// Every function here is host-callable too: the host evaluates per-primitive constants (the box-face
+// shading frames, pt_kernels.hip) with the very same expression trees, compiled by the same hipcc run with
+// the same -ffp-contract=off, so a tabulated value has the bits the kernel would have computed.
+#define PTD_FN __host__ __device__ __forceinline__
+
 namespace ptd {
 
 // src/utilities.h:20-26
@@ -25,24 +30,24 @@ namespace ptd {
 
 struct f3 { float x, y, z; };
 
-__device__ __forceinline__ f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
-__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
-__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
-__device__ __forceinline__ f3 operator*(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
-__device__ __forceinline__ f3 operator*(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
-__device__ __forceinline__ f3 operator/(f3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
-__device__ __forceinline__ f3 neg(f3 a) { return mk(-a.x, -a.y, -a.z); }
+PTD_FN f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+PTD_FN f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+PTD_FN f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+PTD_FN f3 operator*(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+PTD_FN f3 operator*(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+PTD_FN f3 operator/(f3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+PTD_FN f3 neg(f3 a) { return mk(-a.x, -a.y, -a.z); }
 // glm::dot / cross / length / normalize (src/glm/core/func_geometric.inl:158-167,199-211,59-68,239-248)
-__device__ __forceinline__ float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
-__device__ __forceinline__ f3 cross(f3 x, f3 y) {
+PTD_FN float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+PTD_FN f3 cross(f3 x, f3 y) {
     return mk(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y);
 }
-__device__ __forceinline__ float length(f3 a) { return __builtin_sqrtf(dot(a, a)); }
-__device__ __forceinline__ f3 normalize(f3 a) { return a * (1.0f / __builtin_sqrtf(dot(a, a))); }
+PTD_FN float length(f3 a) { return __builtin_sqrtf(dot(a, a)); }
+PTD_FN f3 normalize(f3 a) { return a * (1.0f / __builtin_sqrtf(dot(a, a))); }
 
 // ---------------------------------------------------------------- RNG ------------------
 // hash: src/intersections.h:26-34
-__device__ __forceinline__ uint32_t hash(uint32_t a) {
+PTD_FN uint32_t hash(uint32_t a) {
     a = (a + 0x7ed55d16u) + (a << 12);
     a = (a ^ 0xc761c23cu) ^ (a >> 19);
     a = (a + 0x165667b1u) + (a << 5);
@@ -53,26 +58,27 @@ __device__ __forceinline__ uint32_t hash(uint32_t a) {
 }
 // thrust::default_random_engine = minstd_rand (a = 48271, m = 2^31-1); m is a Mersenne prime so
 // x mod m folds as (x & m) + (x >> 31) with one conditional subtract (no 64-bit division).
-__device__ __forceinline__ uint32_t lcg_seed(uint32_t s) {
+PTD_FN uint32_t lcg_seed(uint32_t s) {
     uint32_t r = (s & 0x7FFFFFFFu) + (s >> 31);
     if (r >= 0x7FFFFFFFu) r -= 0x7FFFFFFFu;
     return r == 0u ? 1u : r;
 }
-__device__ __forceinline__ uint32_t lcg_next(uint32_t x) {
+PTD_FN uint32_t lcg_next(uint32_t x) {
     uint64_t p = (uint64_t)x * 48271ull;
     uint32_t r = (uint32_t)(p & 0x7FFFFFFFull) + (uint32_t)(p >> 31);
     if (r >= 0x7FFFFFFFu) r -= 0x7FFFFFFFu;
     return r;
 }
 // uniform_real_distribution<float>(0,1): float(x - 1) / 2^31
-__device__ __forceinline__ float u01(uint32_t x) { return (float)(x - 1u) / 2147483648.0f; }
-// build-defined stream seed
-__device__ __forceinline__ uint32_t stream_seed(uint32_t pixel, uint32_t iteration, uint32_t stream) {
-    return hash(hash(pixel) + 0x9E3779B9u * iteration + stream);
+PTD_FN float u01(uint32_t x) { return (float)(x - 1u) / 2147483648.0f; }
+// build-defined stream seed: ONE hash of an injective mix of (pixel, iteration, stream)
+// -- `hash` is a bijection on 32 bits, so two streams coincide only where the mixes do
+PTD_FN uint32_t stream_seed(uint32_t pixel, uint32_t iteration, uint32_t stream) {
+    return hash(pixel + 0x9E3779B9u * iteration + 0x85EBCA6Bu * stream);
 }
 
 // sin/cos of a in [0, 2pi]: Cody-Waite by pi/2 + Cephes-coefficient polynomials, +,-,* only.
-__device__ __forceinline__ void sincos_poly(float a, float &s, float &c) {
+PTD_FN void sincos_poly(float a, float &s, float &c) {
     int k = (int)((a * 0.636619772367581343f) + 0.5f);
     float kf = (float)k;
     float r = ((a - (kf * 1.5703125f)) - (kf * 4.837512969970703125e-4f)) - (kf * 7.54978995489188216e-8f);
@@ -115,13 +121,13 @@ struct MatRec {
 };
 
 // multiplyMV with w = 1 (src/intersections.h:53-59): ((m0*x + m1*y) + m2*z) + m3*1
-__device__ __forceinline__ f3 mul_point(const float *m, f3 v) {
+PTD_FN f3 mul_point(const float *m, f3 v) {
     return mk((((m[0] * v.x) + (m[1] * v.y)) + (m[2] * v.z)) + m[3],
               (((m[4] * v.x) + (m[5] * v.y)) + (m[6] * v.z)) + m[7],
               (((m[8] * v.x) + (m[9] * v.y)) + (m[10] * v.z)) + m[11]);
 }
 // multiplyMV with w = 0: the "+ m3*0" term only affects the sign of a zero result
-__device__ __forceinline__ f3 mul_vector(const float *m, f3 v) {
+PTD_FN f3 mul_vector(const float *m, f3 v) {
     return mk(((m[0] * v.x) + (m[1] * v.y)) + (m[2] * v.z),
               ((m[4] * v.x) + (m[5] * v.y)) + (m[6] * v.z),
               ((m[8] * v.x) + (m[9] * v.y)) + (m[10] * v.z));
@@ -129,7 +135,7 @@ __device__ __forceinline__ f3 mul_vector(const float *m, f3 v) {
 
 // sphereIntersectionTest (src/intersections.h:168-204) incl. getPointOnRay's second
 // normalize and its double-precision `t-.0001` (:46-48).  Returns world distance or -1.
-__device__ __forceinline__ float sphere_test(const float *inv, const float *xf, f3 o, f3 d, f3 &P, f3 &N) {
+PTD_FN float sphere_test(const float *inv, const float *xf, f3 o, f3 d, f3 &P, f3 &N) {
     f3 ro = mul_point(inv, o);
     f3 rd = normalize(mul_vector(inv, d));
     float b = dot(ro, rd);
@@ -154,8 +160,10 @@ __device__ __forceinline__ float sphere_test(const float *inv, const float *xf, 
 
 // boxIntersectionTest on the unit cube (src/intersections.h:73-164); inside_hits is the
 // build's extension for refractive boxes (a ray starting inside leaves through tmax).
-__device__ __forceinline__ float box_test(const float *inv, const float *xf, int inside_hits, f3 o, f3 d,
-                                          f3 &P, f3 &N) {
+// box_test_face returns the world distance (or -1), the hit point and the FACE instead of the normal:
+// face = col + 3*(negative side), col = 0,1,2 for x,y,z in the reference's cascade order +x,+y,+z,-x,-y,-z
+// (:143-155), -1 when the cascade finds no face.  N = multiplyMV(transform,(n,0)) = +-column `col` of xf.
+PTD_FN float box_test_face(const float *inv, const float *xf, int inside_hits, f3 o, f3 d, f3 &P, int &face) {
     f3 ro = mul_point(inv, o);
     f3 p1 = mul_point(inv, o + d);
     f3 rd = normalize(p1 - ro);
@@ -179,36 +187,49 @@ __device__ __forceinline__ float box_test(const float *inv, const float *xf, int
         th = tmax;
     }
     f3 os = ro + rd * th;
-    // face cascade +x,+y,+z,-x,-y,-z (:143-155); N = multiplyMV(transform,(n,0)) = +-column
-    int col = -1;
-    float sgn = 1.0f;
-    if (fabsf(os.x - .5f) < .001f) { col = 0; }
-    else if (fabsf(os.y - .5f) < .001f) { col = 1; }
-    else if (fabsf(os.z - .5f) < .001f) { col = 2; }
-    else if (fabsf(os.x + .5f) < .001f) { col = 0; sgn = -1.0f; }
-    else if (fabsf(os.y + .5f) < .001f) { col = 1; sgn = -1.0f; }
-    else if (fabsf(os.z + .5f) < .001f) { col = 2; sgn = -1.0f; }
+    int fc = -1;
+    if (fabsf(os.x - .5f) < .001f) { fc = 0; }
+    else if (fabsf(os.y - .5f) < .001f) { fc = 1; }
+    else if (fabsf(os.z - .5f) < .001f) { fc = 2; }
+    else if (fabsf(os.x + .5f) < .001f) { fc = 3; }
+    else if (fabsf(os.y + .5f) < .001f) { fc = 4; }
+    else if (fabsf(os.z + .5f) < .001f) { fc = 5; }
     f3 wp = mul_point(xf, os);
     P = wp;
-    if (col < 0) N = mk(0.0f, 0.0f, 0.0f);
-    else N = mk(xf[col] * sgn, xf[4 + col] * sgn, xf[8 + col] * sgn);
+    face = fc;
     return length(wp - o);
+}
+// the reference's normal of a box face: +-column of transform, unnormalised (:161); (0,0,0) for face -1
+PTD_FN f3 box_face_normal(const float *xf, int face) {
+    if (face < 0) return mk(0.0f, 0.0f, 0.0f);
+    const int col = face >= 3 ? face - 3 : face;
+    const float sgn = face >= 3 ? -1.0f : 1.0f;
+    return mk(xf[col] * sgn, xf[4 + col] * sgn, xf[8 + col] * sgn);
+}
+PTD_FN float box_test(const float *inv, const float *xf, int inside_hits, f3 o, f3 d, f3 &P, f3 &N) {
+    int face = -1;
+    f3 p = mk(0.0f, 0.0f, 0.0f);
+    const float depth = box_test_face(inv, xf, inside_hits, o, d, p, face);
+    if (depth < 0.0f) return depth;                      // a miss leaves P, N untouched like the reference
+    P = p;
+    N = box_face_normal(xf, face);
+    return depth;
 }
 
 // ---------------------------------------------------------------- light sampling -------
 // getRadiuses / getRandomPointOnCube / getRandomPointOnSphere (src/intersections.h:207-286): no
 // call sites in the reference; provided (and parity-tested against the oracle) for next-event
 // estimation.  Quirks kept: float seed truncated to unsigned, sphere sampler non-uniform / NaN-prone.
-__device__ __forceinline__ f3 get_radiuses(const float *xf) {
+PTD_FN f3 get_radiuses(const float *xf) {
     const f3 origin = mul_point(xf, mk(0.0f, 0.0f, 0.0f));
     const f3 xmax = mul_point(xf, mk(.5f, 0.0f, 0.0f));
     const f3 ymax = mul_point(xf, mk(0.0f, .5f, 0.0f));
     const f3 zmax = mul_point(xf, mk(0.0f, 0.0f, .5f));
     return mk(length(xmax - origin), length(ymax - origin), length(zmax - origin));
 }
-__device__ __forceinline__ float dist_ab(uint32_t x, float a, float b) { return (u01(x) * (b - a)) + a; }
+PTD_FN float dist_ab(uint32_t x, float a, float b) { return (u01(x) * (b - a)) + a; }
 
-__device__ __forceinline__ f3 random_point_on_cube(const float *xf, float randomSeed) {
+PTD_FN f3 random_point_on_cube(const float *xf, float randomSeed) {
     uint32_t st = lcg_seed(hash((uint32_t)randomSeed));
     const f3 radii = get_radiuses(xf);
     const float side1 = radii.x * radii.y * 4.0f;
@@ -228,7 +249,7 @@ __device__ __forceinline__ f3 random_point_on_cube(const float *xf, float random
     return mul_point(xf, point);
 }
 
-__device__ __forceinline__ f3 random_point_on_sphere(const float *xf, float randomSeed) {
+PTD_FN f3 random_point_on_sphere(const float *xf, float randomSeed) {
     uint32_t st = lcg_seed(hash((uint32_t)randomSeed));
     st = lcg_next(st); const float x = dist_ab(st, -0.5f, 0.5f);
     st = lcg_next(st); const float y = dist_ab(st, -0.5f, 0.5f);
@@ -241,7 +262,7 @@ __device__ __forceinline__ f3 random_point_on_sphere(const float *xf, float rand
 // Light sample for next-event estimation: the reference's samplers above plus
 // the reciprocal of the density they induce per unit world area (cube: 1/totalarea; sphere: |z|
 // on the unit-diameter sphere over the area scale (2*radii.x)^2).  false = unusable sample.
-__device__ __forceinline__ bool sample_light(const float *xf, int type, float randomSeed, f3 &Q, float &inv_pdf_area) {
+PTD_FN bool sample_light(const float *xf, int type, float randomSeed, f3 &Q, float &inv_pdf_area) {
     const f3 radii = get_radiuses(xf);
     bool ok = false;
     Q = mk(0.0f, 0.0f, 0.0f);
@@ -268,30 +289,38 @@ __device__ __forceinline__ bool sample_light(const float *xf, int type, float ra
 }
 
 // ---------------------------------------------------------------- scatter --------------
-// calculateRandomDirectionInHemisphere (src/interactions.h:62-87)
-__device__ __forceinline__ f3 hemisphere(f3 normal, float xi1, float xi2) {
-    float up = __builtin_sqrtf(xi1);
-    float over = __builtin_sqrtf(1.0f - up * up);
-    float around = xi2 * PT_TWO_PI;
+// calculateRandomDirectionInHemisphere (src/interactions.h:62-87), in two halves: the tangent frame depends only
+// on the normal (tabulated per box face by the host, pt_kernels.hip), the combination on the two random numbers.
+PTD_FN void hemisphere_frame(f3 normal, f3 &p1, f3 &p2) {
     f3 dnn;
     if (fabsf(normal.x) < PT_SQRT_OF_ONE_THIRD) dnn = mk(1.0f, 0.0f, 0.0f);
     else if (fabsf(normal.y) < PT_SQRT_OF_ONE_THIRD) dnn = mk(0.0f, 1.0f, 0.0f);
     else dnn = mk(0.0f, 0.0f, 1.0f);
-    f3 p1 = normalize(cross(normal, dnn));
-    f3 p2 = normalize(cross(normal, p1));
+    p1 = normalize(cross(normal, dnn));
+    p2 = normalize(cross(normal, p1));
+}
+PTD_FN f3 hemisphere_combine(f3 normal, f3 p1, f3 p2, float xi1, float xi2) {
+    float up = __builtin_sqrtf(xi1);
+    float over = __builtin_sqrtf(1.0f - up * up);
+    float around = xi2 * PT_TWO_PI;
     float sn, cs;
     sincos_poly(around, sn, cs);
     return ((normal * up) + (p1 * (cs * over))) + (p2 * (sn * over));
 }
+PTD_FN f3 hemisphere(f3 normal, float xi1, float xi2) {
+    f3 p1, p2;
+    hemisphere_frame(normal, p1, p2);
+    return hemisphere_combine(normal, p1, p2, xi1, xi2);
+}
 // calculateReflectionDirection (stub src/interactions.h:47-50)
-__device__ __forceinline__ f3 reflect_dir(f3 n, f3 i) {
+PTD_FN f3 reflect_dir(f3 n, f3 i) {
     float k = 2.0f * dot(n, i);
     return i - n * k;
 }
 // calculateFresnel + calculateTransmissionDirection (stubs src/interactions.h:42-44,53-59)
 // evaluated together: returns the reflection coefficient (1 = total internal reflection) and
 // the transmitted direction.
-__device__ __forceinline__ float fresnel_transmit(f3 n, f3 i, float ior_i, float ior_t, f3 &tdir) {
+PTD_FN float fresnel_transmit(f3 n, f3 i, float ior_i, float ior_t, f3 &tdir) {
     float eta = ior_i / ior_t;
     float c = -dot(n, i);
     float k = 1.0f - ((eta * eta) * (1.0f - (c * c)));
@@ -308,7 +337,7 @@ __device__ __forceinline__ float fresnel_transmit(f3 n, f3 i, float ior_i, float
 // The calculateBSDF contract (stub src/interactions.h:96-103; spec DESIGN.md section 3.5).
 // Returns 0 diffuse, 1 reflected, 2 transmitted, 3 ended on an emitter (L set), 4 degenerate.
 // (Single exit with value selects: keeps o/d/thr in registers instead of scratch.)
-__device__ __forceinline__ int scatter(const MatRec &m, f3 P, f3 N, float u_sel, float xi1, float xi2,
+PTD_FN int scatter(const MatRec &m, f3 P, f3 N, float u_sel, float xi1, float xi2,
                                        f3 &o, f3 &d, f3 &thr, f3 &L) {
     int code;
     f3 no = o, nd = d, nthr = thr, nL = mk(0.0f, 0.0f, 0.0f);
@@ -353,9 +382,91 @@ __device__ __forceinline__ int scatter(const MatRec &m, f3 P, f3 N, float u_sel,
     return code;
 }
 
+// Shading frames of a box primitive, one record per axis (column of transform): everything scatter() derives
+// from the face normal alone.  A hit on the +-`col` face has N = +-column (box_face_normal), so
+// n = N/|N| = +-n and nf, the normal facing the incoming ray, is n or its exact negation; the tangent frame
+// hemisphere_frame(nf) has two possible values per axis.  The host fills these with the functions above
+// (same expression trees, same compiler run): the bits are the ones the generic path computes per ray.
+struct __attribute__((aligned(16))) FaceFrame {
+    float n[4];               // normalize(column); n[3] = 1 if |column|^2 > 0 else 0 (degenerate: scatter code 4)
+    float p1p[4], p2p[4];     // hemisphere_frame(+n)
+    float p1m[4], p2m[4];     // hemisphere_frame(-n)
+};
+
+PTD_FN void make_face_frame(const float *xf, int col, FaceFrame *out) {
+    const f3 N = mk(xf[col], xf[4 + col], xf[8 + col]);
+    const float nn = dot(N, N);
+    const f3 n = N * (1.0f / __builtin_sqrtf(nn));
+    f3 a, b, c, d;
+    hemisphere_frame(n, a, b);
+    hemisphere_frame(neg(n), c, d);
+    out->n[0] = n.x; out->n[1] = n.y; out->n[2] = n.z; out->n[3] = nn > 0.0f ? 1.0f : 0.0f;
+    out->p1p[0] = a.x; out->p1p[1] = a.y; out->p1p[2] = a.z; out->p1p[3] = 0.0f;
+    out->p2p[0] = b.x; out->p2p[1] = b.y; out->p2p[2] = b.z; out->p2p[3] = 0.0f;
+    out->p1m[0] = c.x; out->p1m[1] = c.y; out->p1m[2] = c.z; out->p1m[3] = 0.0f;
+    out->p2m[0] = d.x; out->p2m[1] = d.y; out->p2m[2] = d.z; out->p2m[3] = 0.0f;
+}
+
+// scatter() for a box hit given as (face, the primitive's three FaceFrames): same results bit for bit, without the
+// per-ray normalisation and tangent frame (2 of the 3 normalize + both cross products of the generic path).
+PTD_FN int scatter_box(const MatRec &m, f3 P, int face, const FaceFrame *frames, float u_sel, float xi1, float xi2,
+                       f3 &o, f3 &d, f3 &thr, f3 &L) {
+    int code;
+    f3 no = o, nd = d, nthr = thr, nL = mk(0.0f, 0.0f, 0.0f);
+    if (m.emittance > 0.0f) {
+        const f3 e = mk(m.color[0], m.color[1], m.color[2]) * m.emittance;
+        nL = thr * e;
+        code = 3;
+    } else {
+        const int col = face >= 3 ? face - 3 : (face < 0 ? 0 : face);
+        const FaceFrame *F = frames + col;
+        const float4 nv = *reinterpret_cast<const float4 *>(F->n);
+        if (face < 0 || !(nv.w > 0.0f)) {
+            code = 4;
+        } else {
+            const bool minus = face >= 3;
+            const f3 np = mk(nv.x, nv.y, nv.z);
+            const f3 n = minus ? neg(np) : np;
+            const float cosi = dot(n, d);
+            const bool back = cosi > 0.0f;
+            const f3 nf = back ? neg(n) : n;
+            const f3 spec = mk(m.spec[0], m.spec[1], m.spec[2]);
+            if (m.refr > 0.0f) {
+                const float ior = (m.ior > 0.0f) ? m.ior : 1.0f;
+                const bool entering = !back;
+                const float ior_i = entering ? 1.0f : ior, ior_t = entering ? ior : 1.0f;
+                f3 tdir;
+                const float R = fresnel_transmit(nf, d, ior_i, ior_t, tdir);
+                nthr = thr * spec;
+                const bool refl = u_sel < R;
+                const f3 rdir = reflect_dir(nf, d);
+                const f3 o_r = P + nf * PT_RAY_BIAS, o_t = P - nf * PT_TRANSMIT_BIAS;
+                nd = refl ? rdir : tdir;
+                no = refl ? o_r : o_t;
+                code = refl ? 1 : 2;
+            } else if (m.refl > 0.0f) {
+                nd = reflect_dir(nf, d);
+                nthr = thr * spec;
+                no = P + nf * PT_RAY_BIAS;
+                code = 1;
+            } else {
+                const bool flip = minus != back;                   // nf == -normalize(column)
+                const float4 a = *reinterpret_cast<const float4 *>(flip ? F->p1m : F->p1p);
+                const float4 b = *reinterpret_cast<const float4 *>(flip ? F->p2m : F->p2p);
+                nd = hemisphere_combine(nf, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), xi1, xi2);
+                nthr = thr * mk(m.color[0], m.color[1], m.color[2]);
+                no = P + nf * PT_RAY_BIAS;
+                code = 0;
+            }
+        }
+    }
+    o = no; d = nd; thr = nthr; L = nL;
+    return code;
+}
+
 // ---------------------------------------------------------------- camera ---------------
 // per-pixel half of raycastFromCameraKernel (src/raytraceKernel.cu:62-74)
-__device__ __forceinline__ void camera_ray(const CamRec &c, uint32_t pixel, uint32_t iteration, f3 &o, f3 &d) {
+PTD_FN void camera_ray(const CamRec &c, uint32_t pixel, uint32_t iteration, f3 &o, f3 &d) {
     int x = (int)(pixel % (uint32_t)c.W), y = (int)(pixel / (uint32_t)c.W);
     f3 E = mk(c.E[0], c.E[1], c.E[2]);
     float fx = (float)x, fy = (float)y;

@@ -958,6 +958,322 @@ __global__ __launch_bounds__(kBlock, PT_SEG_WAVES) void k_bounce_defer(SegArgs a
     }
 }
 
+// ------------------------------------------------------------------ bounce, typed work queues ----
+// `ordering = 1` (what bench.py runs).  Measured on the Cornell box: a ray has 0.78 candidate primitives on
+// average -- four in ten have none, most of the rest exactly one -- yet in the lock-step kernels every 64-ray
+// group pays whole rounds of the exact cube test, the exact sphere test and the shading for the lanes that
+// need them.  Here the unit of work is ONE EXACT TEST of one ray against its nearest untested candidate, and
+// the wave regroups rays between stages so that every stage runs on (nearly) full waves:
+//
+//   FRESH   64 rays of the wave's input stream: load origin + direction only (bounce 0: the camera ray),
+//           conservative culling pass over the LDS table (wave-uniform primitive index) -> candidate mask +
+//           nearest candidate.  Rays without candidates are finished.  The others are pushed -- origin,
+//           direction, pool index, remaining mask, best depth, winner/next ids: 10 dwords -- on one of two
+//           wave-private LDS stacks by the TYPE of that nearest candidate (cubes grow up, spheres grow down
+//           in one buffer).
+//   TEST    pops up to 64 records of one type (a full wave whenever a stack holds 64) and runs that exact
+//           reference test on all lanes.  A ray with further candidates that could still win or tie (their
+//           conservative entry distance re-checked against the best hit) goes back on a stack; otherwise it
+//           is resolved and is shaded at once: throughput and pixel word are fetched from the input pool only
+//           now (four dwords that finished rays never load), cube hits take their unit normal and tangent
+//           frame from the per-face table (FaceFrame, filled by the host with the same arithmetic), and the
+//           survivor is written to the wave's output stream.
+//
+// Output: a wave fills ITS OWN segments (seg = wave slot + k * slots) one after the other, so segments stay
+// dense whatever died (no half-empty groups in late bounces).  Survivors therefore keep their wave but
+// neither their segment nor their order (deterministic; image, live counts and the set of rays are those of
+// the stable kernel -- asserted).  Nothing leaves the wave: no barrier, no atomics on the data path.
+constexpr uint32_t kQCap = 160;          // records per wave, both stacks together (>= 64 + 2*48)
+constexpr uint32_t kQFields = 10;        // ox oy oz dx dy dz idx|pixelword mask best (hit+1)|(next<<8)
+
+#ifndef PT_Q_WAVES
+#define PT_Q_WAVES 5
+#endif
+
+__device__ __forceinline__ uint32_t wave_rank(u64 ballot) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
+}
+
+template <bool LAST, bool GEN>
+__global__ __launch_bounds__(kBlock, PT_Q_WAVES) void k_bounce_q(SegArgs a, const GeomRec *__restrict__ geoms,
+                                                                 const MatRec *__restrict__ mats, const FaceFrame *__restrict__ frames) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t *ctrl = reinterpret_cast<uint32_t *>(smem);   // [0] survivors, [1] emitted (block sums)
+    if (threadIdx.x < 2) ctrl[threadIdx.x] = 0u;
+    GeomRec *lg;
+    MatRec *lm;
+    stage_tables(smem, geoms, a.G, mats, a.M, true, lg, lm);        // ends with __syncthreads()
+
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
+    const uint32_t wslot = blockIdx.x * kWaves + wave, nslots = gridDim.x * kWaves;
+    const size_t cap = a.cap;
+    const uint32_t S = a.seg_slots;
+    uint32_t emitted = 0u, survivors = 0u;
+    float *q = reinterpret_cast<float *>(smem + tables_bytes(a.G, a.M, true)) + (size_t)wave * kQCap * kQFields;
+
+    uint32_t *bank = a.bank ? a.sync->counts_b : a.sync->counts;
+    if (GEN && blockIdx.x == 0 && threadIdx.x < 72) {
+        uint32_t *other = a.bank ? a.sync->counts : a.sync->counts_b;
+        a.sync->totals[threadIdx.x] += other[threadIdx.x];
+        other[threadIdx.x] = 0u;
+        if (threadIdx.x == 0) bank[0] = a.n_rays;
+    }
+
+    uint32_t boxbits = 0u;                                 // wave-uniform; G <= 32 on this path
+    for (int j = 0; j < a.G; ++j)
+        if (lg[j].type == 1) boxbits |= 1u << j;
+
+    // input cursor: the wave's segments in order, skipping empty ones
+    auto seg_count = [&](uint32_t sg) -> uint32_t {
+        if (GEN) {
+            const uint32_t f0 = sg * S;
+            return f0 >= a.n_rays ? 0u : (a.n_rays - f0 < S ? a.n_rays - f0 : S);
+        }
+        return a.cnt_in[sg];
+    };
+    uint32_t seg = wslot, n = 0u, g = 0u;
+    while (seg < a.nseg_in) {
+        n = seg_count(seg);
+        if (n) break;
+        seg += nslots;
+    }
+    bool fresh_left = seg < a.nseg_in;
+    // output cursor
+    uint32_t oseg = wslot, ofill = 0u;
+    uint32_t nbox = 0u, nsph = 0u;
+    const float kInf = 100000000000000000.0f;
+
+    for (;;) {
+        int act;
+        if (nbox >= 64u) act = 1;
+        else if (nsph >= 64u) act = 2;
+        else if (fresh_left && nbox + nsph <= kQCap - 64u) act = 0;
+        else if (nbox + nsph == 0u) break;
+        else act = nbox >= nsph ? 1 : 2;
+
+        f3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+        uint32_t idx = 0u, mask = 0u, hitnext = 0u;
+        float best = kInf;
+        bool push = false;
+        int next_j = 0;
+
+        bool alive = false;
+        f3 thr = mk(0, 0, 0);
+        uint32_t pv = 0u;
+
+        if (act == 0) {
+            // ---------------------------------------------------------------- FRESH
+            const uint32_t k = g + lane;
+            const bool valid = k < n;
+            const uint32_t ray = seg * S + k;
+            if (valid) {
+                if (GEN) {
+                    const uint32_t slot = a.batch > 1u ? ray / a.n_own : 0u;
+                    const uint32_t local = ray - slot * a.n_own;
+                    const uint32_t W = (uint32_t)a.cam.W;
+                    const uint32_t lr = local / W, x = local - lr * W;
+                    const uint32_t pixel = (lr * (uint32_t)a.cam.row_stride + (uint32_t)a.cam.row_offset) * W + x;
+                    camera_ray(a.cam, pixel, a.iteration + slot, o, d);
+                    idx = pixel | (slot << 24);                       // bounce 0 carries the pixel word itself
+                } else {
+                    __builtin_assume(ray < (1u << 29));
+                    const float *in = a.in;
+                    o = mk(in[ray], (in + cap)[ray], (in + 2 * cap)[ray]);
+                    d = mk((in + 3 * cap)[ray], (in + 4 * cap)[ray], (in + 5 * cap)[ray]);
+                    idx = ray;
+                }
+            }
+            g += 64u;
+            if (g >= n) {                                             // next non-empty segment of this wave
+                g = 0u; n = 0u;
+                seg += nslots;
+                while (seg < a.nseg_in) {
+                    n = seg_count(seg);
+                    if (n) break;
+                    seg += nslots;
+                }
+                fresh_left = seg < a.nseg_in;
+            }
+            // conservative candidate mask + nearest candidate, wave-uniform primitive index
+            const CullRay cr = make_cull_ray(o, d);
+            float near_t = 3.0e38f;
+            for (int j = 0; j < a.G; ++j) {
+                float tn;
+                const GeomRec &gr = lg[j];
+                const int type = gr.type;
+                bool keep = false;
+                if (type == 1) keep = cull_box(gr.bmin, gr.bmax, cr, tn);
+                else if (type == 0) keep = cull_sphere(gr.bmin, gr.bmax, cr, tn);
+                if (keep) {
+                    mask |= 1u << j;
+                    if (tn < near_t) { near_t = tn; next_j = j; }
+                }
+            }
+            if (!valid) mask = 0u;
+            push = mask != 0u;
+            mask &= ~(1u << next_j);
+            hitnext = 0u;                                             // no hit yet
+        } else {
+            // ---------------------------------------------------------------- TEST (one type per group)
+            const bool isb = act == 1;
+            const uint32_t have = isb ? nbox : nsph;
+            const uint32_t cnt = have < 64u ? have : 64u;
+            const bool valid = lane < cnt;
+            const uint32_t pos = isb ? (have - cnt + lane) : (kQCap - 1u - (have - cnt + lane));
+            if (isb) nbox -= cnt; else nsph -= cnt;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (valid) {
+                const float *r = q + pos;
+                o = mk(r[0 * kQCap], r[1 * kQCap], r[2 * kQCap]);
+                d = mk(r[3 * kQCap], r[4 * kQCap], r[5 * kQCap]);
+                idx = __float_as_uint(r[6 * kQCap]);
+                mask = __float_as_uint(r[7 * kQCap]);
+                best = r[8 * kQCap];
+                hitnext = __float_as_uint(r[9 * kQCap]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int j = (int)((hitnext >> 8) & 31u);
+            int hit = (int)(hitnext & 63u) - 1;
+            const GeomRec *gr = lg + j;                               // per-lane gather from the LDS table
+            f3 P = mk(0, 0, 0), N = mk(0, 0, 0);
+            int face = -1;
+            float depth = -1.0f;
+            if (valid) {
+                if (isb) depth = box_test_face(gr->inv, gr->xf, gr->inside_hits, o, d, P, face);
+                else depth = sphere_test(gr->inv, gr->xf, o, d, P, N);
+            }
+            // nearest-hit update of the reference loop (first strictly nearer wins; ties to the lower index)
+            const bool cur_wins = valid && depth > -PT_EPSILON && (depth < best || (depth == best && j < hit));
+            if (cur_wins) { best = depth; hit = j; }
+            // further candidates: drop those entered farther than the best hit, pick the nearest of the rest
+            next_j = -1;
+            if (valid && mask != 0u) {
+                const CullRay cr = make_cull_ray(o, d);
+                float nt = 3.0e38f;
+                uint32_t m = mask;
+                while (m) {
+                    const int jj = __builtin_ctz(m);
+                    m &= m - 1u;
+                    const GeomRec *gb = lg + jj;
+                    float tn;
+                    if ((boxbits >> jj) & 1u) (void)cull_box(gb->bmin, gb->bmax, cr, tn);
+                    else (void)cull_sphere(gb->bmin, gb->bmax, cr, tn);
+                    if (hit >= 0 && tn - gb->slack > best) { mask &= ~(1u << jj); continue; }
+                    if (tn < nt) { nt = tn; next_j = jj; }
+                }
+            }
+            const bool more = next_j >= 0;
+            const bool resolved = valid && !more;
+            // a resolved ray whose winner is an EARLIER candidate has lost that hit's point: test it once more, alone
+            const bool retest = resolved && hit >= 0 && !cur_wins;
+            const bool shade = resolved && cur_wins;
+            if (retest) { next_j = hit; mask = 0u; best = kInf; hit = -1; }
+            else if (more) mask &= ~(1u << next_j);
+            else next_j = 0;
+            push = more || retest;
+            hitnext = (uint32_t)(hit + 1);
+
+            // ---------------------------------------------------------------- shade the resolved hits
+            if (shade) {
+                if (GEN) { pv = idx; thr = mk(1.0f, 1.0f, 1.0f); }
+                else {
+                    __builtin_assume(idx < (1u << 29));
+                    const float *in = a.in;
+                    thr = mk((in + 6 * cap)[idx], (in + 7 * cap)[idx], (in + 8 * cap)[idx]);
+                    pv = reinterpret_cast<const uint32_t *>(in + 9 * cap)[idx];
+                }
+                const uint32_t slot = a.batch > 1u ? pv >> 24 : 0u, pixel = pv & a.pix_mask;
+                const MatRec m = lm[gr->mat];                         // gr = the winner (hit == j here)
+                if (LAST && !(m.emittance > 0.0f)) {
+                    alive = true;                                     // depth exhausted: alive, contributes 0
+                } else {
+                    const uint32_t iteration = a.iteration + slot;
+                    uint32_t st = lcg_seed(stream_seed(pixel, iteration, 1u + (uint32_t)a.bounce));
+                    st = lcg_next(st); const float u_sel = u01(st);
+                    st = lcg_next(st); const float xi1 = u01(st);
+                    st = lcg_next(st); const float xi2 = u01(st);
+                    f3 L = mk(0.0f, 0.0f, 0.0f);
+                    int code;
+                    if (isb) code = scatter_box(m, P, face, frames + 3 * j, u_sel, xi1, xi2, o, d, thr, L);
+                    else code = scatter(m, P, N, u_sel, xi1, xi2, o, d, thr, L);
+                    if (code == 3) {
+                        float *acc = a.batch > 1u ? a.planes + (size_t)slot * a.plane_stride : a.image;
+                        float *px = acc + (size_t)pixel * 3;
+                        px[0] = px[0] + L.x; px[1] = px[1] + L.y; px[2] = px[2] + L.z;
+                        emitted++;
+                    }
+                    alive = code <= 2;
+                }
+            }
+        }
+
+        // -------------------------------------------------------------------- push (FRESH and re-queued rays)
+        {
+            const bool tobox = push && ((boxbits >> next_j) & 1u);
+            const u64 bb = __ballot(tobox), sb = __ballot(push && !tobox);
+            if (bb | sb) {
+                if (push) {
+                    const uint32_t pos = tobox ? nbox + wave_rank(bb) : kQCap - 1u - (nsph + wave_rank(sb));
+                    float *r = q + pos;
+                    r[0 * kQCap] = o.x; r[1 * kQCap] = o.y; r[2 * kQCap] = o.z;
+                    r[3 * kQCap] = d.x; r[4 * kQCap] = d.y; r[5 * kQCap] = d.z;
+                    r[6 * kQCap] = __uint_as_float(idx);
+                    r[7 * kQCap] = __uint_as_float(mask);
+                    r[8 * kQCap] = best;
+                    r[9 * kQCap] = __uint_as_float(hitnext | ((uint32_t)next_j << 8));
+                }
+                nbox += (uint32_t)__popcll(bb);
+                nsph += (uint32_t)__popcll(sb);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+
+        // -------------------------------------------------------------------- survivors -> the wave's output stream
+        if (act != 0) {
+            const u64 ballot = __ballot(alive);
+            const uint32_t na = (uint32_t)__popcll(ballot);
+            if (!LAST && na) {
+                if (alive) {
+                    uint32_t p = ofill + wave_rank(ballot);
+                    const uint32_t sg = p >= S ? oseg + nslots : oseg;
+                    p = p >= S ? p - S : p;
+                    const uint32_t oi = sg * S + p;
+                    __builtin_assume(oi < (1u << 29));
+                    float *out = a.out;
+                    out[oi] = o.x; (out + cap)[oi] = o.y; (out + 2 * cap)[oi] = o.z;
+                    (out + 3 * cap)[oi] = d.x; (out + 4 * cap)[oi] = d.y; (out + 5 * cap)[oi] = d.z;
+                    (out + 6 * cap)[oi] = thr.x; (out + 7 * cap)[oi] = thr.y; (out + 8 * cap)[oi] = thr.z;
+                    reinterpret_cast<uint32_t *>(out + 9 * cap)[oi] = pv;
+                }
+                ofill += na;
+                if (ofill >= S) {
+                    if (lane == 0) a.cnt_out[oseg] = S;
+                    oseg += nslots;
+                    ofill -= S;
+                }
+            }
+            survivors += na;
+        }
+    }
+    // close the output stream: the partly filled segment, then zeros for the wave's unused ones
+    if (!LAST && lane == 0) {
+        uint32_t sg = oseg, c = ofill;
+        while (sg < a.nseg_out) { a.cnt_out[sg] = c; c = 0u; sg += nslots; }
+    }
+
+    for (int sft = 32; sft > 0; sft >>= 1) emitted += __shfl_down(emitted, sft);
+    if (lane == 0) {
+        if (survivors) atomicAdd(&ctrl[0], survivors);
+        if (emitted) atomicAdd(&ctrl[1], emitted);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (ctrl[0]) atomicAdd(&bank[a.bounce + 1], ctrl[0]);
+        if (ctrl[1]) atomicAdd(&a.sync->emitted, (u64)ctrl[1]);
+    }
+}
+
 // ------------------------------------------------------------------ bounce, binned ordering -----
 // `ordering = 2`.  The sparse-work queue regroups rays AFTER they turned out to need several exact
 // tests; this variant sorts them BEFORE: when a ray is scattered, its NEW direction is run through the
@@ -1510,7 +1826,9 @@ struct pt_context {
     uint32_t max_chunks = 0, rpt = 3, status_words = 0;
     bool seg_mode = true;            // wave-autonomous segmented compaction (cfg.compaction == 0)
     bool cull = true;                // AABB candidate culling in front of the exact tests (cfg.culling == 0)
-    bool defer = false;              // sparse-work queue kernel (cfg.ordering == 1; needs LDS geometry, G <= 32)
+    bool defer = false;              // sparse-work queue kernel (cfg.ordering == 3: round 1's ring of complex rays; LDS geometry, G <= 32)
+    bool queue = false;              // typed work-queue kernel (cfg.ordering == 1; LDS geometry, G <= 32, no merging)
+    FaceFrame *d_frames = nullptr;   // [G][3] shading frames of the box primitives (k_bounce_q)
     bool binned = false;             // two-ended binned compaction (cfg.ordering == 2; LDS geometry, G <= 32)
     bool use_bvh = false;            // candidate-list kernel (cfg.bvh 1 = BVH walk, 2 = uniform scan; <= 256 primitives)
     BvhNode *d_nodes = nullptr; BoundRec *d_bounds = nullptr; unsigned char *d_order = nullptr;
@@ -1602,6 +1920,8 @@ void free_scene_buffers(pt_context *c) {
     c->d_planes = nullptr;
     if (c->d_lights) (void)hipFree(c->d_lights);
     c->d_lights = nullptr;
+    if (c->d_frames) (void)hipFree(c->d_frames);
+    c->d_frames = nullptr;
     if (c->d_nodes) (void)hipFree(c->d_nodes);
     if (c->d_bounds) (void)hipFree(c->d_bounds);
     if (c->d_order) (void)hipFree(c->d_order);
@@ -1776,8 +2096,20 @@ int launch_defer_t(pt_context *c, const SegArgs &a) {
     return PT_OK;
 }
 
+template <bool LAST, bool GEN>
+int launch_q_t(pt_context *c, const SegArgs &a) {
+    hipLaunchKernelGGL((k_bounce_q<LAST, GEN>), dim3(c->grid_bounce), dim3(kBlock), c->lds_bytes, c->stream, a,
+                       (const GeomRec *)c->d_geoms, (const MatRec *)c->d_mats, (const FaceFrame *)c->d_frames);
+    HIPCHK(hipGetLastError());
+    return PT_OK;
+}
+
 int launch_seg(pt_context *c, const SegArgs &a, bool last, bool gen) {
     Scoped s(c, 1);
+    if (c->queue) {
+        if (gen) return last ? launch_q_t<true, true>(c, a) : launch_q_t<false, true>(c, a);
+        return last ? launch_q_t<true, false>(c, a) : launch_q_t<false, false>(c, a);
+    }
     if (c->nee) {
         if (gen) return last ? launch_nee_t<true, true>(c, a) : launch_nee_t<false, true>(c, a);
         return last ? launch_nee_t<true, false>(c, a) : launch_nee_t<false, false>(c, a);
@@ -1809,7 +2141,7 @@ int launch_seg(pt_context *c, const SegArgs &a, bool last, bool gen) {
 uint32_t seg_slots_for(const pt_context *c, uint32_t n_rays) {
     if (c->cfg.chunk_rays > 0) return c->seg_slots;
     // the sparse-work queue drains once per segment (one partly filled group): longer segments there
-    const bool longseg = c->defer || c->binned;
+    const bool longseg = c->defer || c->binned || c->queue;
     const uint32_t slots = (uint32_t)c->grid_bounce * kWaves * (longseg ? 2u : 4u);
     uint32_t S = (((n_rays + slots - 1) / slots) + 63u) & ~63u;
     if (S < 192u) S = 192u;
@@ -2055,10 +2387,11 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     }
     c->seg_mode = (c->cfg.compaction == 0);
     c->cull = (c->cfg.culling == 0) && c->seg_mode;
-    c->defer = c->cull && c->cfg.ordering == 1 && c->cfg.geometry_path == 0 && G <= 32 && c->cfg.mode == 0;
+    c->defer = c->cull && c->cfg.ordering == 3 && c->cfg.geometry_path == 0 && G <= 32 && c->cfg.mode == 0;
+    c->queue = c->cull && c->cfg.ordering == 1 && c->cfg.geometry_path == 0 && G <= 32 && c->cfg.mode == 0 && c->cfg.merge_floor <= 0;
     c->use_bvh = c->cull && c->cfg.mode == 0 && G <= 256 && (c->cfg.bvh == 1 || c->cfg.bvh == 2);   // opt-in: measured slower than block-wise culling
     c->binned = c->cull && c->cfg.ordering == 2 && c->cfg.geometry_path == 0 && G <= 32 && c->cfg.mode == 0;
-    if (c->use_bvh) { c->defer = false; c->binned = false; }
+    if (c->use_bvh) { c->defer = false; c->binned = false; c->queue = false; }
     c->geom_lds = (c->cfg.geometry_path == 0);
     c->nee = c->cfg.direct_light != 0 && c->cfg.mode == 0;
     if (c->nee) {
@@ -2067,7 +2400,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
             pth::set_error("pt_upload_scene: direct_light needs compaction=0, culling=0, geometry_path=0");
             return PT_ERR_ARGUMENT;
         }
-        c->defer = false; c->binned = false; c->use_bvh = false;
+        c->defer = false; c->binned = false; c->use_bvh = false; c->queue = false;
         std::vector<uint32_t> lights;
         for (int i = 0; i < G; ++i)
             if (mats[geoms[i].materialid].emittance > 0.0f) lights.push_back((uint32_t)i);
@@ -2106,7 +2439,8 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
 
     // LDS budget: tables (+ the ray stage of the look-back variant)
     uint32_t tb = tables_bytes(G, M, c->geom_lds);
-    const uint32_t stage_bytes = c->seg_mode ? (c->defer ? kWaves * kQueueCap * kQueueFields * (uint32_t)sizeof(float) : 0u)
+    const uint32_t stage_bytes = c->seg_mode ? (c->defer ? kWaves * kQueueCap * kQueueFields * (uint32_t)sizeof(float)
+                                                : c->queue ? kWaves * kQCap * kQFields * (uint32_t)sizeof(float) : 0u)
                                              : kBlock * c->rpt * kFields * (uint32_t)sizeof(float);
     if (c->geom_lds && tb + stage_bytes > 160u * 1024u) {   // table too large for LDS: scalar-load path
         if (c->nee) { pth::set_error("pt_upload_scene: direct_light needs the geometry table in LDS (%d primitives do not fit)", G); return PT_ERR_ARGUMENT; }
@@ -2115,7 +2449,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     }
     c->lds_bytes = c->use_bvh ? bvh_lds_bytes(G, M, c->nnodes) : tb + stage_bytes;
     // 33..256 primitives with the table in LDS: the mask-register / packed-list variant (PT_WIDE=0 turns it off)
-    c->wide = c->cull && c->geom_lds && !c->nee && !c->use_bvh && !c->defer && !c->binned && c->cfg.mode == 0 && G > 32 && G <= 256;
+    c->wide = c->cull && c->geom_lds && !c->nee && !c->use_bvh && !c->defer && !c->binned && !c->queue && c->cfg.mode == 0 && G > 32 && G <= 256;
     if (const char *wv = getenv("PT_WIDE")) if (atoi(wv) == 0) c->wide = false;
     const void *fns[8] = {
         reinterpret_cast<const void *>(&k_bounce<true, false>), reinterpret_cast<const void *>(&k_bounce<false, false>),
@@ -2150,6 +2484,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
                        : c->nee ? nee_fns[0]
                        : c->binned ? reinterpret_cast<const void *>(&k_bounce_bin<false, false>)
                        : c->use_bvh ? reinterpret_cast<const void *>(&k_bounce_bvh<false, false>)
+                       : c->queue ? reinterpret_cast<const void *>(&k_bounce_q<false, false>)
                        : c->defer ? reinterpret_cast<const void *>(&k_bounce_defer<false, false>) : fns[(c->seg_mode ? 4 : 0) + (c->geom_lds ? 0 : 1)];
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, kBlock, c->lds_bytes) != hipSuccess || occ < 1) occ = 2;
         per_cu = occ;
@@ -2221,6 +2556,17 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     HIPCHK(hipMalloc(&c->d_display, (size_t)W * H * sizeof(uchar4)));
     HIPCHK(hipMemcpy(c->d_geoms, g.data(), (size_t)G * sizeof(GeomRec), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_mats, m.data(), (size_t)M * sizeof(MatRec), hipMemcpyHostToDevice));
+    if (c->queue) {
+        // per box primitive and axis: unit normal + the two tangent frames scatter() would derive per ray; evaluated
+        // here with the kernels' own functions (pt_device.hpp is host-callable, same -ffp-contract=off build)
+        std::vector<FaceFrame> fr((size_t)G * 3);
+        memset(fr.data(), 0, fr.size() * sizeof(FaceFrame));
+        for (int i = 0; i < G; ++i)
+            if (g[i].type == 1)
+                for (int col = 0; col < 3; ++col) make_face_frame(g[i].xf, col, &fr[(size_t)i * 3 + col]);
+        HIPCHK(hipMalloc(&c->d_frames, fr.size() * sizeof(FaceFrame)));
+        HIPCHK(hipMemcpy(c->d_frames, fr.data(), fr.size() * sizeof(FaceFrame), hipMemcpyHostToDevice));
+    }
     pth::camera_basis(cam, &c->cfg, &c->cam);
     c->scene_ready = true;
     return PT_OK;

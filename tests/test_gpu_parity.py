@@ -190,7 +190,7 @@ def test_accumulation_continues_from_host_image(pt, cornell200):
 
 
 @pytest.mark.parametrize("kw", [dict(geometry_path=1), dict(chunk_rays=64), dict(batch=1), dict(batch=2), dict(batch=3, chunk_rays=100), dict(chunk_rays=64, merge_floor=3000), dict(chunk_rays=64, merge_floor=50, batch=2), dict(chunk_rays=1000), dict(chunk_rays=16, merge_floor=1), dict(chunk_rays=100, merge_floor=7), dict(blocks_per_cu=1),
-                                dict(culling=1), dict(culling=1, geometry_path=1), dict(bvh=1), dict(bvh=1, batch=3, chunk_rays=64), dict(ordering=2), dict(ordering=2, batch=2, chunk_rays=100), dict(ordering=2, batch=1), dict(ordering=1), dict(ordering=1, batch=2), dict(ordering=1, chunk_rays=100, merge_floor=7), dict(ordering=1, batch=1, chunk_rays=64),
+                                dict(culling=1), dict(culling=1, geometry_path=1), dict(bvh=1), dict(bvh=1, batch=3, chunk_rays=64), dict(ordering=2), dict(ordering=2, batch=2, chunk_rays=100), dict(ordering=2, batch=1), dict(ordering=1), dict(ordering=1, batch=2), dict(ordering=1, chunk_rays=100, merge_floor=7), dict(ordering=1, batch=1, chunk_rays=64), dict(ordering=1, chunk_rays=128, blocks_per_cu=1), dict(ordering=3), dict(ordering=3, batch=2, chunk_rays=100),
                                 dict(compaction=1), dict(compaction=1, chunk_rays=256), dict(compaction=1, chunk_rays=1024, geometry_path=1)])
 def test_launch_variants_are_bit_identical(pt, cornell200, kw):
     ref = make_tracer(cornell200)
@@ -508,10 +508,10 @@ def test_light_sampling_helpers_bit_exact(pt):
 @pytest.mark.parametrize("scene_name,depth,iters,kw", [
     ("sampleScene", 8, 5, dict()), ("cornell_mirror", 8, 4, dict()), ("cornell_glass_4k", 12, 3, dict()),
     ("cornell_glass_4k", 6, 3, dict(camera_mode=1, antialias=1, aperture=0.25, focal_distance=12.0))])
-@pytest.mark.parametrize("ordering", [1, 2])
+@pytest.mark.parametrize("ordering", [1, 2, 3])
 def test_sparse_work_queue_ordering_is_bit_identical(pt, scene_name, depth, iters, kw, ordering):
-    """ordering=1 (dense regrouping of rays with non-trivial candidate sets): same image, same live
-    counts as the oracle; the pool holds the same rays segment by segment."""
+    """ordering=1 (typed work queues: one exact test per stage on full waves), 2 (binned) and 3 (round 1's ring of
+    complex rays): same image, same live counts as the oracle; the pool holds the same set of rays."""
     sc = orc.load_golden_scene(scene_name).with_resolution(200, 150)
     tr = make_tracer(sc, depth=depth, ordering=ordering, **kw)
     tr.set_image(None); tr.render(1, iters)
