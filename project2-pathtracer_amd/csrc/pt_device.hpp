@@ -389,9 +389,9 @@ PTD_FN int scatter(const MatRec &m, f3 P, f3 N, float u_sel, float xi1, float xi
 // (same expression trees, same compiler run): the bits are the ones the generic path computes per ray.
 struct __attribute__((aligned(16))) FaceFrame {
     float n[4];               // normalize(column); n[3] = 1 if |column|^2 > 0 else 0 (degenerate: scatter code 4)
-    float p1p[4], p2p[4];     // hemisphere_frame(+n)
-    float p1m[4], p2m[4];     // hemisphere_frame(-n)
-};
+    float pp[6];              // hemisphere_frame(+n): p1, p2
+    float pm[6];              // hemisphere_frame(-n): p1, p2
+};                            // 64 bytes
 
 PTD_FN void make_face_frame(const float *xf, int col, FaceFrame *out) {
     const f3 N = mk(xf[col], xf[4 + col], xf[8 + col]);
@@ -401,10 +401,8 @@ PTD_FN void make_face_frame(const float *xf, int col, FaceFrame *out) {
     hemisphere_frame(n, a, b);
     hemisphere_frame(neg(n), c, d);
     out->n[0] = n.x; out->n[1] = n.y; out->n[2] = n.z; out->n[3] = nn > 0.0f ? 1.0f : 0.0f;
-    out->p1p[0] = a.x; out->p1p[1] = a.y; out->p1p[2] = a.z; out->p1p[3] = 0.0f;
-    out->p2p[0] = b.x; out->p2p[1] = b.y; out->p2p[2] = b.z; out->p2p[3] = 0.0f;
-    out->p1m[0] = c.x; out->p1m[1] = c.y; out->p1m[2] = c.z; out->p1m[3] = 0.0f;
-    out->p2m[0] = d.x; out->p2m[1] = d.y; out->p2m[2] = d.z; out->p2m[3] = 0.0f;
+    out->pp[0] = a.x; out->pp[1] = a.y; out->pp[2] = a.z; out->pp[3] = b.x; out->pp[4] = b.y; out->pp[5] = b.z;
+    out->pm[0] = c.x; out->pm[1] = c.y; out->pm[2] = c.z; out->pm[3] = d.x; out->pm[4] = d.y; out->pm[5] = d.z;
 }
 
 // scatter() for a box hit given as (face, the primitive's three FaceFrames): same results bit for bit, without the
@@ -420,12 +418,12 @@ PTD_FN int scatter_box(const MatRec &m, f3 P, int face, const FaceFrame *frames,
     } else {
         const int col = face >= 3 ? face - 3 : (face < 0 ? 0 : face);
         const FaceFrame *F = frames + col;
-        const float4 nv = *reinterpret_cast<const float4 *>(F->n);
-        if (face < 0 || !(nv.w > 0.0f)) {
+        const float nvx = F->n[0], nvy = F->n[1], nvz = F->n[2], nvw = F->n[3];
+        if (face < 0 || !(nvw > 0.0f)) {
             code = 4;
         } else {
             const bool minus = face >= 3;
-            const f3 np = mk(nv.x, nv.y, nv.z);
+            const f3 np = mk(nvx, nvy, nvz);
             const f3 n = minus ? neg(np) : np;
             const float cosi = dot(n, d);
             const bool back = cosi > 0.0f;
@@ -451,9 +449,8 @@ PTD_FN int scatter_box(const MatRec &m, f3 P, int face, const FaceFrame *frames,
                 code = 1;
             } else {
                 const bool flip = minus != back;                   // nf == -normalize(column)
-                const float4 a = *reinterpret_cast<const float4 *>(flip ? F->p1m : F->p1p);
-                const float4 b = *reinterpret_cast<const float4 *>(flip ? F->p2m : F->p2p);
-                nd = hemisphere_combine(nf, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), xi1, xi2);
+                const float *fr = flip ? F->pm : F->pp;
+                nd = hemisphere_combine(nf, mk(fr[0], fr[1], fr[2]), mk(fr[3], fr[4], fr[5]), xi1, xi2);
                 nthr = thr * mk(m.color[0], m.color[1], m.color[2]);
                 no = P + nf * PT_RAY_BIAS;
                 code = 0;

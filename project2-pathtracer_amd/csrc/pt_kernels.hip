@@ -989,9 +989,16 @@ constexpr uint32_t kQFields = 10;        // ox oy oz dx dy dz idx|pixelword mask
 #ifndef PT_Q_WAVES
 #define PT_Q_WAVES 5
 #endif
+#ifndef PT_Q_PREFETCH
+#define PT_Q_PREFETCH 0                  // 1: origin + direction of the next fresh group are loaded one stage ahead (+6 VGPRs)
+#endif
 
 __device__ __forceinline__ uint32_t wave_rank(u64 ballot) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
+}
+
+__host__ __device__ inline uint32_t q_lds_offset(int G, int M) {
+    return tables_bytes(G, M, true) + (uint32_t)G * 3u * (uint32_t)sizeof(FaceFrame);
 }
 
 template <bool LAST, bool GEN>
@@ -1002,6 +1009,13 @@ __global__ __launch_bounds__(kBlock, PT_Q_WAVES) void k_bounce_q(SegArgs a, cons
     if (threadIdx.x < 2) ctrl[threadIdx.x] = 0u;
     GeomRec *lg;
     MatRec *lm;
+    // LDS: ctrl | materials | geometry | face frames | 4 wave-private queue buffers
+    FaceFrame *lf = reinterpret_cast<FaceFrame *>(smem + tables_bytes(a.G, a.M, true));
+    {
+        uint32_t *fd = reinterpret_cast<uint32_t *>(lf);
+        const uint32_t *fs = reinterpret_cast<const uint32_t *>(frames);
+        for (uint32_t i = threadIdx.x; i < (uint32_t)a.G * 3u * (uint32_t)(sizeof(FaceFrame) / 4); i += blockDim.x) fd[i] = fs[i];
+    }
     stage_tables(smem, geoms, a.G, mats, a.M, true, lg, lm);        // ends with __syncthreads()
 
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
@@ -1009,7 +1023,7 @@ __global__ __launch_bounds__(kBlock, PT_Q_WAVES) void k_bounce_q(SegArgs a, cons
     const size_t cap = a.cap;
     const uint32_t S = a.seg_slots;
     uint32_t emitted = 0u, survivors = 0u;
-    float *q = reinterpret_cast<float *>(smem + tables_bytes(a.G, a.M, true)) + (size_t)wave * kQCap * kQFields;
+    float *q = reinterpret_cast<float *>(smem + q_lds_offset(a.G, a.M)) + (size_t)wave * kQCap * kQFields;
 
     uint32_t *bank = a.bank ? a.sync->counts_b : a.sync->counts;
     if (GEN && blockIdx.x == 0 && threadIdx.x < 72) {
@@ -1038,6 +1052,22 @@ __global__ __launch_bounds__(kBlock, PT_Q_WAVES) void k_bounce_q(SegArgs a, cons
         seg += nslots;
     }
     bool fresh_left = seg < a.nseg_in;
+    // origin + direction of the NEXT fresh group are loaded one stage ahead (their HBM latency passes under the
+    // stages in between); bounce 0 computes its camera rays instead
+    f3 pf_o = mk(0, 0, 0), pf_d = mk(0, 0, 1);
+    auto prefetch = [&]() {
+        if (PT_Q_PREFETCH && !GEN && fresh_left) {
+            const uint32_t k = g + lane;
+            if (k < n) {
+                const uint32_t ray = seg * S + k;
+                __builtin_assume(ray < (1u << 29));
+                const float *in = a.in;
+                pf_o = mk(in[ray], (in + cap)[ray], (in + 2 * cap)[ray]);
+                pf_d = mk((in + 3 * cap)[ray], (in + 4 * cap)[ray], (in + 5 * cap)[ray]);
+            }
+        }
+    };
+    prefetch();
     // output cursor
     uint32_t oseg = wslot, ofill = 0u;
     uint32_t nbox = 0u, nsph = 0u;
@@ -1076,10 +1106,13 @@ __global__ __launch_bounds__(kBlock, PT_Q_WAVES) void k_bounce_q(SegArgs a, cons
                     camera_ray(a.cam, pixel, a.iteration + slot, o, d);
                     idx = pixel | (slot << 24);                       // bounce 0 carries the pixel word itself
                 } else {
-                    __builtin_assume(ray < (1u << 29));
-                    const float *in = a.in;
-                    o = mk(in[ray], (in + cap)[ray], (in + 2 * cap)[ray]);
-                    d = mk((in + 3 * cap)[ray], (in + 4 * cap)[ray], (in + 5 * cap)[ray]);
+                    if (PT_Q_PREFETCH) { o = pf_o; d = pf_d; }
+                    else {
+                        __builtin_assume(ray < (1u << 29));
+                        const float *in = a.in;
+                        o = mk(in[ray], (in + cap)[ray], (in + 2 * cap)[ray]);
+                        d = mk((in + 3 * cap)[ray], (in + 4 * cap)[ray], (in + 5 * cap)[ray]);
+                    }
                     idx = ray;
                 }
             }
@@ -1094,6 +1127,7 @@ __global__ __launch_bounds__(kBlock, PT_Q_WAVES) void k_bounce_q(SegArgs a, cons
                 }
                 fresh_left = seg < a.nseg_in;
             }
+            prefetch();
             // conservative candidate mask + nearest candidate, wave-uniform primitive index
             const CullRay cr = make_cull_ray(o, d);
             float near_t = 3.0e38f;
@@ -1130,6 +1164,14 @@ __global__ __launch_bounds__(kBlock, PT_Q_WAVES) void k_bounce_q(SegArgs a, cons
                 mask = __float_as_uint(r[7 * kQCap]);
                 best = r[8 * kQCap];
                 hitnext = __float_as_uint(r[9 * kQCap]);
+                // throughput + pixel word of the ray: requested now, needed only if this test resolves the ray
+                if (GEN) { pv = idx; thr = mk(1.0f, 1.0f, 1.0f); }
+                else {
+                    __builtin_assume(idx < (1u << 29));
+                    const float *in = a.in;
+                    thr = mk((in + 6 * cap)[idx], (in + 7 * cap)[idx], (in + 8 * cap)[idx]);
+                    pv = reinterpret_cast<const uint32_t *>(in + 9 * cap)[idx];
+                }
             }
             __builtin_amdgcn_wave_barrier();
             const int j = (int)((hitnext >> 8) & 31u);
@@ -1175,13 +1217,6 @@ __global__ __launch_bounds__(kBlock, PT_Q_WAVES) void k_bounce_q(SegArgs a, cons
 
             // ---------------------------------------------------------------- shade the resolved hits
             if (shade) {
-                if (GEN) { pv = idx; thr = mk(1.0f, 1.0f, 1.0f); }
-                else {
-                    __builtin_assume(idx < (1u << 29));
-                    const float *in = a.in;
-                    thr = mk((in + 6 * cap)[idx], (in + 7 * cap)[idx], (in + 8 * cap)[idx]);
-                    pv = reinterpret_cast<const uint32_t *>(in + 9 * cap)[idx];
-                }
                 const uint32_t slot = a.batch > 1u ? pv >> 24 : 0u, pixel = pv & a.pix_mask;
                 const MatRec m = lm[gr->mat];                         // gr = the winner (hit == j here)
                 if (LAST && !(m.emittance > 0.0f)) {
@@ -1194,12 +1229,14 @@ __global__ __launch_bounds__(kBlock, PT_Q_WAVES) void k_bounce_q(SegArgs a, cons
                     st = lcg_next(st); const float xi2 = u01(st);
                     f3 L = mk(0.0f, 0.0f, 0.0f);
                     int code;
-                    if (isb) code = scatter_box(m, P, face, frames + 3 * j, u_sel, xi1, xi2, o, d, thr, L);
+                    if (isb) code = scatter_box(m, P, face, lf + 3 * j, u_sel, xi1, xi2, o, d, thr, L);
                     else code = scatter(m, P, N, u_sel, xi1, xi2, o, d, thr, L);
                     if (code == 3) {
+                        // one path per pixel and plane in a launch: a single IEEE addition per word, so the memory-side
+                        // atomic gives the bits of the read-modify-write -- without a load the wave would wait for
                         float *acc = a.batch > 1u ? a.planes + (size_t)slot * a.plane_stride : a.image;
                         float *px = acc + (size_t)pixel * 3;
-                        px[0] = px[0] + L.x; px[1] = px[1] + L.y; px[2] = px[2] + L.z;
+                        (void)unsafeAtomicAdd(px, L.x); (void)unsafeAtomicAdd(px + 1, L.y); (void)unsafeAtomicAdd(px + 2, L.z);
                         emitted++;
                     }
                     alive = code <= 2;
@@ -2440,7 +2477,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     // LDS budget: tables (+ the ray stage of the look-back variant)
     uint32_t tb = tables_bytes(G, M, c->geom_lds);
     const uint32_t stage_bytes = c->seg_mode ? (c->defer ? kWaves * kQueueCap * kQueueFields * (uint32_t)sizeof(float)
-                                                : c->queue ? kWaves * kQCap * kQFields * (uint32_t)sizeof(float) : 0u)
+                                                : c->queue ? (uint32_t)G * 3u * (uint32_t)sizeof(FaceFrame) + kWaves * kQCap * kQFields * (uint32_t)sizeof(float) : 0u)
                                              : kBlock * c->rpt * kFields * (uint32_t)sizeof(float);
     if (c->geom_lds && tb + stage_bytes > 160u * 1024u) {   // table too large for LDS: scalar-load path
         if (c->nee) { pth::set_error("pt_upload_scene: direct_light needs the geometry table in LDS (%d primitives do not fit)", G); return PT_ERR_ARGUMENT; }

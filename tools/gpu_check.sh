@@ -14,7 +14,9 @@ if [ "${1:-}" = "--no-tests" ]; then shift; else
 fi
 for spec in "$@"; do
   label=${spec%%:*}; args=${spec#*:}
-  timeout -k 10 400 python3 bench.py $args > $OUT/${TAG}_bench_$label.log 2>&1 || { echo "bench $label FAILED"; tail -20 $OUT/${TAG}_bench_$label.log; exit 1; }
+  lib=""
+  case "$args" in LIB=*) lib=$(pwd)/project2-pathtracer_amd/build/variants/${args%% *}; lib=${lib/LIB=/}.so; args=${args#* };; esac
+  PTMI355_LIB=$lib timeout -k 10 400 python3 bench.py $args > $OUT/${TAG}_bench_$label.log 2>&1 || { echo "bench $label FAILED"; tail -20 $OUT/${TAG}_bench_$label.log; exit 1; }
   python3 - "$OUT/${TAG}_bench_$label.log" "$label" <<'PY'
 import json,sys
 for l in open(sys.argv[1]):

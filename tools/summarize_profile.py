@@ -16,11 +16,11 @@ from collections import defaultdict
 
 def short(name):
     import re
-    m = re.search(r"(k_bounce_defer|k_bounce_seg|k_bounce)<([a-z, ]+)>", name)
+    m = re.search(r"(k_bounce_defer|k_bounce_q|k_bounce_seg|k_bounce)<([a-z, ]+)>", name)
     if m:
         flags = [x.strip() == "true" for x in m.group(2).split(",")]
-        if m.group(1) == "k_bounce_defer":
-            return "k_bounce_defer<%s%s>" % ("last" if flags[0] else "mid", ",gen" if flags[1] else "")
+        if m.group(1) in ("k_bounce_defer", "k_bounce_q"):
+            return "%s<%s%s>" % (m.group(1), "last" if flags[0] else "mid", ",gen" if flags[1] else "")
         tag = "%s<%s,%s" % (m.group(1), "lds" if flags[0] else "scalar", "last" if flags[1] else "mid")
         if len(flags) > 2:
             tag += ",cull" if flags[2] else ",brute"
