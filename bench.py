@@ -386,7 +386,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "repeats": R, "value_is": "median of %d identical K-step passes" % R,
             "value_min": round(W * H * args.steps * depth / max(passes) / 1e6, 1), "value_max": round(W * H * args.steps * depth / min(passes) / 1e6, 1),
-            "spread": round((max(passes) - min(passes)) / elapsed, 4),
+            "spread": round((max(passes) - min(passes)) / elapsed, 4), "passes_ms": [round(p * 1e3, 4) for p in passes],
             "live_Mray_bounces_per_s": round(live_per_step * args.steps / elapsed / 1e6, 1),
             "config": {"workload": desc, "scene": scene_path, "resolution": [W, H], "bounces": depth,
                        "rays_per_step": W * H, "sharding": "rows interleaved over %d GPU(s), 1 RCCL %s per frame" % (world, "gather of the owned rows" if args.exchange == "gather" else "reduce"),

@@ -164,7 +164,9 @@ __device__ __forceinline__ bool cull_sphere(const float *bmin, const float *bmax
 }
 
 #ifdef PT_CULL_STATS
-__device__ unsigned long long g_cull_stats[8];   // [0] groups, [1] box iters, [2] box active lanes, [3] sph iters, [4] sph active lanes, [5] candidates
+__device__ unsigned long long g_cull_stats[16];  // [8..15] typed-queue kernel: fresh groups, fresh valid lanes, box groups, box lanes, sphere groups, sphere lanes, shaded lanes, re-queued lanes
+__device__ __forceinline__ void qstat(int i, unsigned long long v) { if ((threadIdx.x & 63) == 0 && v) atomicAdd(&g_cull_stats[i], v); }
+// [0..7] lock-step kernels: [0] groups, [1] box iters, [2] box active lanes, [3] sph iters, [4] sph active lanes, [5] candidates
 #endif
 
 template <bool GEOM_LDS>
@@ -959,62 +961,84 @@ __global__ __launch_bounds__(kBlock, PT_SEG_WAVES) void k_bounce_defer(SegArgs a
 }
 
 // ------------------------------------------------------------------ bounce, typed work queues ----
-// `ordering = 1` (what bench.py runs).  Measured on the Cornell box: a ray has 0.78 candidate primitives on
-// average -- four in ten have none, most of the rest exactly one -- yet in the lock-step kernels every 64-ray
-// group pays whole rounds of the exact cube test, the exact sphere test and the shading for the lanes that
-// need them.  Here the unit of work is ONE EXACT TEST of one ray against its nearest untested candidate, and
-// the wave regroups rays between stages so that every stage runs on (nearly) full waves:
+// `ordering = 1` (what bench.py runs).  Measured on the Cornell box (tools/qstats.py): a ray has 0.93 candidate
+// primitives on average -- a third have none, most of the rest exactly one, 0.82 exact tests per ray are needed in
+// all -- yet in the lock-step kernels every 64-ray group pays whole rounds of the exact cube test, the exact sphere
+// test and the shading for the lanes that need them.  Here the unit of work is ONE EXACT TEST of a ray against its
+// nearest candidate, and the wave regroups rays between the two stages so that both run on (nearly) full waves:
 //
-//   FRESH   64 rays of the wave's input stream: load origin + direction only (bounce 0: the camera ray),
-//           conservative culling pass over the LDS table (wave-uniform primitive index) -> candidate mask +
-//           nearest candidate.  Rays without candidates are finished.  The others are pushed -- origin,
-//           direction, pool index, remaining mask, best depth, winner/next ids: 10 dwords -- on one of two
-//           wave-private LDS stacks by the TYPE of that nearest candidate (cubes grow up, spheres grow down
-//           in one buffer).
-//   TEST    pops up to 64 records of one type (a full wave whenever a stack holds 64) and runs that exact
-//           reference test on all lanes.  A ray with further candidates that could still win or tie (their
-//           conservative entry distance re-checked against the best hit) goes back on a stack; otherwise it
-//           is resolved and is shaded at once: throughput and pixel word are fetched from the input pool only
-//           now (four dwords that finished rays never load), cube hits take their unit normal and tangent
-//           frame from the per-face table (FaceFrame, filled by the host with the same arithmetic), and the
-//           survivor is written to the wave's output stream.
+//   FRESH   64 rays of the wave's input stream: load origin + direction only (bounce 0: the camera ray), conservative
+//           culling pass over a compact LDS table of bounds (wave-uniform index, two primitives per trip so that
+//           their LDS reads overlap) -> candidate mask + nearest candidate.  Rays without candidates are finished.
+//           The others are pushed -- origin, direction, pool index, remaining mask, first candidate: 9 dwords -- on
+//           one of two wave-private LDS stacks by the TYPE of that nearest candidate (cubes grow up, spheres grow
+//           down in one buffer).
+//   TEST    pops up to 64 records of one type (a full wave whenever a stack holds 64) and runs that exact reference
+//           test on all lanes.  The few rays (0.04 %) with another candidate that could still win or tie -- its
+//           conservative entry distance is re-checked against the best hit -- take further rounds on the spot.  Then
+//           the hits are shaded at once: throughput and pixel word are fetched from the input pool only now (four
+//           dwords that finished rays never load, requested at pop time), cube hits take their unit normal and
+//           tangent frame from the per-face table (FaceFrame, filled by the host with the same arithmetic), and the
+//           survivors go to the wave's output stream.
 //
-// Output: a wave fills ITS OWN segments (seg = wave slot + k * slots) one after the other, so segments stay
-// dense whatever died (no half-empty groups in late bounces).  Survivors therefore keep their wave but
-// neither their segment nor their order (deterministic; image, live counts and the set of rays are those of
-// the stable kernel -- asserted).  Nothing leaves the wave: no barrier, no atomics on the data path.
-constexpr uint32_t kQCap = 160;          // records per wave, both stacks together (>= 64 + 2*48)
-constexpr uint32_t kQFields = 10;        // ox oy oz dx dy dz idx|pixelword mask best (hit+1)|(next<<8)
+// Output: a wave fills ITS OWN segments (seg = wave slot + k * slots) one after the other, so segments stay dense
+// whatever died (no half-empty groups in late bounces).  Survivors therefore keep their wave but neither their
+// segment nor their order (deterministic; image, live counts and the set of rays are those of the stable kernel --
+// asserted).  Nothing leaves the wave: no barrier, no atomics on the data path; the accumulator takes memory-side
+// float atomics (one addition per word and launch, i.e. the bits of a read-modify-write, without its load).
+#ifndef PT_Q_CAP
+#define PT_Q_CAP 152                     // records per wave, both stacks together: a FRESH group needs 64 free, so
+#endif                                   // stacks of up to 88 wait; 9 dwords x 152 x 4 waves + tables -> 6 blocks / CU
+constexpr uint32_t kQCap = PT_Q_CAP;
+constexpr uint32_t kQFields = 9;         // ox oy oz dx dy dz idx|pixelword mask next
 
 #ifndef PT_Q_WAVES
-#define PT_Q_WAVES 5
+#define PT_Q_WAVES 6
 #endif
-#ifndef PT_Q_PREFETCH
-#define PT_Q_PREFETCH 0                  // 1: origin + direction of the next fresh group are loaded one stage ahead (+6 VGPRs)
+#ifdef PT_MARKERS                        // analysis builds only: named comments in the .s
+#define PT_MARK(name) __asm__ volatile("; PTMARK " name)
+#else
+#define PT_MARK(name)
 #endif
+
+// bounds for the culling pass, sorted cubes first: 32 bytes per primitive
+struct __attribute__((aligned(16))) CullRec {
+    float a[4];              // cube: bmin.xyz, primitive index (int bits)   sphere: centre.xyz, inflated R^2
+    float b[4];              // cube: bmax.xyz, 1 << index (int bits)        sphere: index, 1 << index, -, inflated R
+};
 
 __device__ __forceinline__ uint32_t wave_rank(u64 ballot) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
 }
 
-__host__ __device__ inline uint32_t q_lds_offset(int G, int M) {
-    return tables_bytes(G, M, true) + (uint32_t)G * 3u * (uint32_t)sizeof(FaceFrame);
-}
+__host__ __device__ inline uint32_t q_frames_offset(int G, int M) { return tables_bytes(G, M, true); }
+__host__ __device__ inline uint32_t q_cull_offset(int G, int M) { return q_frames_offset(G, M) + (uint32_t)G * 3u * (uint32_t)sizeof(FaceFrame); }
+__host__ __device__ inline uint32_t q_lds_offset(int G, int M) { return q_cull_offset(G, M) + (uint32_t)G * (uint32_t)sizeof(CullRec); }
+
+struct QTables {
+    const FaceFrame *frames;     // [G][3]
+    const CullRec *cull;         // [nbox + nsph], cubes first
+    int nbox, nsph;
+};
 
 template <bool LAST, bool GEN>
 __global__ __launch_bounds__(kBlock, PT_Q_WAVES) void k_bounce_q(SegArgs a, const GeomRec *__restrict__ geoms,
-                                                                 const MatRec *__restrict__ mats, const FaceFrame *__restrict__ frames) {
+                                                                 const MatRec *__restrict__ mats, QTables qt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *ctrl = reinterpret_cast<uint32_t *>(smem);   // [0] survivors, [1] emitted (block sums)
     if (threadIdx.x < 2) ctrl[threadIdx.x] = 0u;
     GeomRec *lg;
     MatRec *lm;
-    // LDS: ctrl | materials | geometry | face frames | 4 wave-private queue buffers
-    FaceFrame *lf = reinterpret_cast<FaceFrame *>(smem + tables_bytes(a.G, a.M, true));
+    // LDS: ctrl | materials | geometry | face frames | cull records | 4 wave-private queue buffers
+    FaceFrame *lf = reinterpret_cast<FaceFrame *>(smem + q_frames_offset(a.G, a.M));
+    CullRec *lc = reinterpret_cast<CullRec *>(smem + q_cull_offset(a.G, a.M));
     {
         uint32_t *fd = reinterpret_cast<uint32_t *>(lf);
-        const uint32_t *fs = reinterpret_cast<const uint32_t *>(frames);
+        const uint32_t *fs = reinterpret_cast<const uint32_t *>(qt.frames);
         for (uint32_t i = threadIdx.x; i < (uint32_t)a.G * 3u * (uint32_t)(sizeof(FaceFrame) / 4); i += blockDim.x) fd[i] = fs[i];
+        uint32_t *cd = reinterpret_cast<uint32_t *>(lc);
+        const uint32_t *cs = reinterpret_cast<const uint32_t *>(qt.cull);
+        for (uint32_t i = threadIdx.x; i < (uint32_t)(qt.nbox + qt.nsph) * (uint32_t)(sizeof(CullRec) / 4); i += blockDim.x) cd[i] = cs[i];
     }
     stage_tables(smem, geoms, a.G, mats, a.M, true, lg, lm);        // ends with __syncthreads()
 
@@ -1052,22 +1076,17 @@ __global__ __launch_bounds__(kBlock, PT_Q_WAVES) void k_bounce_q(SegArgs a, cons
         seg += nslots;
     }
     bool fresh_left = seg < a.nseg_in;
-    // origin + direction of the NEXT fresh group are loaded one stage ahead (their HBM latency passes under the
-    // stages in between); bounce 0 computes its camera rays instead
-    f3 pf_o = mk(0, 0, 0), pf_d = mk(0, 0, 1);
-    auto prefetch = [&]() {
-        if (PT_Q_PREFETCH && !GEN && fresh_left) {
-            const uint32_t k = g + lane;
-            if (k < n) {
-                const uint32_t ray = seg * S + k;
-                __builtin_assume(ray < (1u << 29));
-                const float *in = a.in;
-                pf_o = mk(in[ray], (in + cap)[ray], (in + 2 * cap)[ray]);
-                pf_d = mk((in + 3 * cap)[ray], (in + 4 * cap)[ray], (in + 5 * cap)[ray]);
-            }
+    // One stage ahead of a FRESH group, twelve lanes touch the 128-byte lines its six loads will read (one dword each):
+    // the HBM latency passes under the stages in between and the loads themselves hit in L2.  One live VGPR.
+    float warm = 0.0f;
+    auto warm_up = [&]() {
+        if (!GEN && fresh_left && lane < 12u) {
+            const uint32_t ray = seg * S + g + (lane & 1u) * 32u;
+            __builtin_assume(ray < (1u << 29));
+            if (g + (lane & 1u) * 32u < n) warm = (a.in + (size_t)(lane >> 1) * cap)[ray];
         }
     };
-    prefetch();
+    warm_up();
     // output cursor
     uint32_t oseg = wslot, ofill = 0u;
     uint32_t nbox = 0u, nsph = 0u;
@@ -1081,21 +1100,15 @@ __global__ __launch_bounds__(kBlock, PT_Q_WAVES) void k_bounce_q(SegArgs a, cons
         else if (nbox + nsph == 0u) break;
         else act = nbox >= nsph ? 1 : 2;
 
-        f3 o = mk(0, 0, 0), d = mk(0, 0, 1);
-        uint32_t idx = 0u, mask = 0u, hitnext = 0u;
-        float best = kInf;
-        bool push = false;
-        int next_j = 0;
-
-        bool alive = false;
-        f3 thr = mk(0, 0, 0);
-        uint32_t pv = 0u;
-
         if (act == 0) {
             // ---------------------------------------------------------------- FRESH
+            PT_MARK("fresh_begin");
+            __asm__ volatile("" :: "v"(warm));                        // the warm-up load is complete before its line is re-read
             const uint32_t k = g + lane;
             const bool valid = k < n;
             const uint32_t ray = seg * S + k;
+            f3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+            uint32_t idx = 0u;
             if (valid) {
                 if (GEN) {
                     const uint32_t slot = a.batch > 1u ? ray / a.n_own : 0u;
@@ -1106,13 +1119,10 @@ __global__ __launch_bounds__(kBlock, PT_Q_WAVES) void k_bounce_q(SegArgs a, cons
                     camera_ray(a.cam, pixel, a.iteration + slot, o, d);
                     idx = pixel | (slot << 24);                       // bounce 0 carries the pixel word itself
                 } else {
-                    if (PT_Q_PREFETCH) { o = pf_o; d = pf_d; }
-                    else {
-                        __builtin_assume(ray < (1u << 29));
-                        const float *in = a.in;
-                        o = mk(in[ray], (in + cap)[ray], (in + 2 * cap)[ray]);
-                        d = mk((in + 3 * cap)[ray], (in + 4 * cap)[ray], (in + 5 * cap)[ray]);
-                    }
+                    __builtin_assume(ray < (1u << 29));
+                    const float *in = a.in;
+                    o = mk(in[ray], (in + cap)[ray], (in + 2 * cap)[ray]);
+                    d = mk((in + 3 * cap)[ray], (in + 4 * cap)[ray], (in + 5 * cap)[ray]);
                     idx = ray;
                 }
             }
@@ -1127,69 +1137,109 @@ __global__ __launch_bounds__(kBlock, PT_Q_WAVES) void k_bounce_q(SegArgs a, cons
                 }
                 fresh_left = seg < a.nseg_in;
             }
-            prefetch();
-            // conservative candidate mask + nearest candidate, wave-uniform primitive index
+            warm_up();
+            PT_MARK("cull_begin");
+            // conservative candidate mask + nearest candidate; wave-uniform table index
             const CullRay cr = make_cull_ray(o, d);
             float near_t = 3.0e38f;
-            for (int j = 0; j < a.G; ++j) {
+            uint32_t mask = 0u, next_j = 0u;
+#pragma unroll 2
+            for (int i = 0; i < qt.nbox; ++i) {
+                const CullRec r = lc[i];
                 float tn;
-                const GeomRec &gr = lg[j];
-                const int type = gr.type;
-                bool keep = false;
-                if (type == 1) keep = cull_box(gr.bmin, gr.bmax, cr, tn);
-                else if (type == 0) keep = cull_sphere(gr.bmin, gr.bmax, cr, tn);
-                if (keep) {
-                    mask |= 1u << j;
-                    if (tn < near_t) { near_t = tn; next_j = j; }
-                }
+                const bool keep = cull_box(r.a, r.b, cr, tn);
+                mask |= keep ? __float_as_uint(r.b[3]) : 0u;
+                const bool nearer = keep && tn < near_t;
+                near_t = nearer ? tn : near_t;
+                next_j = nearer ? __float_as_uint(r.a[3]) : next_j;
             }
+#pragma unroll 2
+            for (int i = qt.nbox; i < qt.nbox + qt.nsph; ++i) {
+                const CullRec r = lc[i];
+                float tn;
+                const bool keep = cull_sphere(r.a, r.b, cr, tn);       // reads a[0..3] and b[3], like bmin / bmax of the full record
+                mask |= keep ? __float_as_uint(r.b[1]) : 0u;
+                const bool nearer = keep && tn < near_t;
+                near_t = nearer ? tn : near_t;
+                next_j = nearer ? __float_as_uint(r.b[0]) : next_j;
+            }
+            PT_MARK("cull_end");
             if (!valid) mask = 0u;
-            push = mask != 0u;
+            const bool push = mask != 0u;
+#ifdef PT_CULL_STATS
+            qstat(8, 1ull); qstat(9, (unsigned long long)__popcll(__ballot(valid)));
+            atomicAdd(&g_cull_stats[5], (unsigned long long)__popc(mask));
+#endif
             mask &= ~(1u << next_j);
-            hitnext = 0u;                                             // no hit yet
-        } else {
-            // ---------------------------------------------------------------- TEST (one type per group)
-            const bool isb = act == 1;
-            const uint32_t have = isb ? nbox : nsph;
-            const uint32_t cnt = have < 64u ? have : 64u;
-            const bool valid = lane < cnt;
-            const uint32_t pos = isb ? (have - cnt + lane) : (kQCap - 1u - (have - cnt + lane));
-            if (isb) nbox -= cnt; else nsph -= cnt;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (valid) {
-                const float *r = q + pos;
-                o = mk(r[0 * kQCap], r[1 * kQCap], r[2 * kQCap]);
-                d = mk(r[3 * kQCap], r[4 * kQCap], r[5 * kQCap]);
-                idx = __float_as_uint(r[6 * kQCap]);
-                mask = __float_as_uint(r[7 * kQCap]);
-                best = r[8 * kQCap];
-                hitnext = __float_as_uint(r[9 * kQCap]);
-                // throughput + pixel word of the ray: requested now, needed only if this test resolves the ray
-                if (GEN) { pv = idx; thr = mk(1.0f, 1.0f, 1.0f); }
-                else {
-                    __builtin_assume(idx < (1u << 29));
-                    const float *in = a.in;
-                    thr = mk((in + 6 * cap)[idx], (in + 7 * cap)[idx], (in + 8 * cap)[idx]);
-                    pv = reinterpret_cast<const uint32_t *>(in + 9 * cap)[idx];
+            const bool tobox = push && ((boxbits >> next_j) & 1u);
+            const u64 bb = __ballot(tobox), sb = __ballot(push && !tobox);
+            if (bb | sb) {
+                if (push) {
+                    const uint32_t pos = tobox ? nbox + wave_rank(bb) : kQCap - 1u - (nsph + wave_rank(sb));
+                    float *r = q + pos;
+                    r[0 * kQCap] = o.x; r[1 * kQCap] = o.y; r[2 * kQCap] = o.z;
+                    r[3 * kQCap] = d.x; r[4 * kQCap] = d.y; r[5 * kQCap] = d.z;
+                    r[6 * kQCap] = __uint_as_float(idx);
+                    r[7 * kQCap] = __uint_as_float(mask);
+                    r[8 * kQCap] = __uint_as_float(next_j);
                 }
+                nbox += (uint32_t)__popcll(bb);
+                nsph += (uint32_t)__popcll(sb);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_wave_barrier();
-            const int j = (int)((hitnext >> 8) & 31u);
-            int hit = (int)(hitnext & 63u) - 1;
+            PT_MARK("fresh_end");
+            continue;
+        }
+
+        // -------------------------------------------------------------------- TEST (one type per group)
+        PT_MARK("test_begin");
+        const bool isb = act == 1;
+        const uint32_t have = isb ? nbox : nsph;
+        const uint32_t cnt = have < 64u ? have : 64u;
+        const bool valid = lane < cnt;
+        const uint32_t pos = isb ? (have - cnt + lane) : (kQCap - 1u - (have - cnt + lane));
+        if (isb) nbox -= cnt; else nsph -= cnt;
+        f3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(0, 0, 0);
+        uint32_t idx = 0u, mask = 0u, pv = 0u;
+        int j = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (valid) {
+            const float *r = q + pos;
+            o = mk(r[0 * kQCap], r[1 * kQCap], r[2 * kQCap]);
+            d = mk(r[3 * kQCap], r[4 * kQCap], r[5 * kQCap]);
+            idx = __float_as_uint(r[6 * kQCap]);
+            mask = __float_as_uint(r[7 * kQCap]);
+            j = (int)__float_as_uint(r[8 * kQCap]);
+            // throughput + pixel word of the ray: requested now, used after the test (nearly every tested ray is a hit)
+            if (GEN) { pv = idx; thr = mk(1.0f, 1.0f, 1.0f); }
+            else {
+                __builtin_assume(idx < (1u << 29));
+                const float *in = a.in;
+                thr = mk((in + 6 * cap)[idx], (in + 7 * cap)[idx], (in + 8 * cap)[idx]);
+                pv = reinterpret_cast<const uint32_t *>(in + 9 * cap)[idx];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        PT_MARK("exact_begin");
+        float best = kInf;
+        int hit = -1, face = -1;
+        f3 P = mk(0, 0, 0), N = mk(0, 0, 0);
+        bool active = valid;
+        for (;;) {                                                    // one round; more only for the rare rays with rivals
+            const bool jb = (boxbits >> j) & 1u;
             const GeomRec *gr = lg + j;                               // per-lane gather from the LDS table
-            f3 P = mk(0, 0, 0), N = mk(0, 0, 0);
-            int face = -1;
+            f3 p = mk(0, 0, 0), nn = mk(0, 0, 0);
+            int fc = -1;
             float depth = -1.0f;
-            if (valid) {
-                if (isb) depth = box_test_face(gr->inv, gr->xf, gr->inside_hits, o, d, P, face);
-                else depth = sphere_test(gr->inv, gr->xf, o, d, P, N);
-            }
+            if (__any(active && jb)) { if (active && jb) depth = box_test_face(gr->inv, gr->xf, gr->inside_hits, o, d, p, fc); }
+            if (__any(active && !jb)) { if (active && !jb) depth = sphere_test(gr->inv, gr->xf, o, d, p, nn); }
             // nearest-hit update of the reference loop (first strictly nearer wins; ties to the lower index)
-            const bool cur_wins = valid && depth > -PT_EPSILON && (depth < best || (depth == best && j < hit));
-            if (cur_wins) { best = depth; hit = j; }
-            // further candidates: drop those entered farther than the best hit, pick the nearest of the rest
-            next_j = -1;
-            if (valid && mask != 0u) {
+            const bool wins = active && depth > -PT_EPSILON && (depth < best || (depth == best && j < hit));
+            if (wins) { best = depth; hit = j; P = p; N = nn; face = fc; }
+            // further candidates: drop those entered farther than the best hit, take the nearest of the rest
+            int next_j = -1;
+            if (active && mask != 0u) {
                 const CullRay cr = make_cull_ray(o, d);
                 float nt = 3.0e38f;
                 uint32_t m = mask;
@@ -1204,94 +1254,72 @@ __global__ __launch_bounds__(kBlock, PT_Q_WAVES) void k_bounce_q(SegArgs a, cons
                     if (tn < nt) { nt = tn; next_j = jj; }
                 }
             }
-            const bool more = next_j >= 0;
-            const bool resolved = valid && !more;
-            // a resolved ray whose winner is an EARLIER candidate has lost that hit's point: test it once more, alone
-            const bool retest = resolved && hit >= 0 && !cur_wins;
-            const bool shade = resolved && cur_wins;
-            if (retest) { next_j = hit; mask = 0u; best = kInf; hit = -1; }
-            else if (more) mask &= ~(1u << next_j);
-            else next_j = 0;
-            push = more || retest;
-            hitnext = (uint32_t)(hit + 1);
-
-            // ---------------------------------------------------------------- shade the resolved hits
-            if (shade) {
-                const uint32_t slot = a.batch > 1u ? pv >> 24 : 0u, pixel = pv & a.pix_mask;
-                const MatRec m = lm[gr->mat];                         // gr = the winner (hit == j here)
-                if (LAST && !(m.emittance > 0.0f)) {
-                    alive = true;                                     // depth exhausted: alive, contributes 0
-                } else {
-                    const uint32_t iteration = a.iteration + slot;
-                    uint32_t st = lcg_seed(stream_seed(pixel, iteration, 1u + (uint32_t)a.bounce));
-                    st = lcg_next(st); const float u_sel = u01(st);
-                    st = lcg_next(st); const float xi1 = u01(st);
-                    st = lcg_next(st); const float xi2 = u01(st);
-                    f3 L = mk(0.0f, 0.0f, 0.0f);
-                    int code;
-                    if (isb) code = scatter_box(m, P, face, lf + 3 * j, u_sel, xi1, xi2, o, d, thr, L);
-                    else code = scatter(m, P, N, u_sel, xi1, xi2, o, d, thr, L);
-                    if (code == 3) {
-                        // one path per pixel and plane in a launch: a single IEEE addition per word, so the memory-side
-                        // atomic gives the bits of the read-modify-write -- without a load the wave would wait for
-                        float *acc = a.batch > 1u ? a.planes + (size_t)slot * a.plane_stride : a.image;
-                        float *px = acc + (size_t)pixel * 3;
-                        (void)unsafeAtomicAdd(px, L.x); (void)unsafeAtomicAdd(px + 1, L.y); (void)unsafeAtomicAdd(px + 2, L.z);
-                        emitted++;
-                    }
-                    alive = code <= 2;
-                }
-            }
+            active = next_j >= 0;
+            if (!__any(active)) break;
+            if (active) { j = next_j; mask &= ~(1u << next_j); }
         }
+        PT_MARK("exact_end");
+        const bool shade = hit >= 0;
+#ifdef PT_CULL_STATS
+        qstat(isb ? 10 : 12, 1ull); qstat(isb ? 11 : 13, (unsigned long long)cnt);
+        qstat(14, (unsigned long long)__popcll(__ballot(shade)));
+#endif
 
-        // -------------------------------------------------------------------- push (FRESH and re-queued rays)
-        {
-            const bool tobox = push && ((boxbits >> next_j) & 1u);
-            const u64 bb = __ballot(tobox), sb = __ballot(push && !tobox);
-            if (bb | sb) {
-                if (push) {
-                    const uint32_t pos = tobox ? nbox + wave_rank(bb) : kQCap - 1u - (nsph + wave_rank(sb));
-                    float *r = q + pos;
-                    r[0 * kQCap] = o.x; r[1 * kQCap] = o.y; r[2 * kQCap] = o.z;
-                    r[3 * kQCap] = d.x; r[4 * kQCap] = d.y; r[5 * kQCap] = d.z;
-                    r[6 * kQCap] = __uint_as_float(idx);
-                    r[7 * kQCap] = __uint_as_float(mask);
-                    r[8 * kQCap] = best;
-                    r[9 * kQCap] = __uint_as_float(hitnext | ((uint32_t)next_j << 8));
+        // -------------------------------------------------------------------- shade the hits
+        PT_MARK("shade_begin");
+        bool alive = false;
+        if (shade) {
+            const uint32_t slot = a.batch > 1u ? pv >> 24 : 0u, pixel = pv & a.pix_mask;
+            const MatRec m = lm[lg[hit].mat];
+            if (LAST && !(m.emittance > 0.0f)) {
+                alive = true;                                         // depth exhausted: alive, contributes 0
+            } else {
+                const uint32_t iteration = a.iteration + slot;
+                uint32_t st = lcg_seed(stream_seed(pixel, iteration, 1u + (uint32_t)a.bounce));
+                st = lcg_next(st); const float u_sel = u01(st);
+                st = lcg_next(st); const float xi1 = u01(st);
+                st = lcg_next(st); const float xi2 = u01(st);
+                f3 L = mk(0.0f, 0.0f, 0.0f);
+                int code = 4;
+                const bool hb = (boxbits >> hit) & 1u;
+                if (__any(hb)) { if (hb) code = scatter_box(m, P, face, lf + 3 * hit, u_sel, xi1, xi2, o, d, thr, L); }
+                if (__any(!hb)) { if (!hb) code = scatter(m, P, N, u_sel, xi1, xi2, o, d, thr, L); }
+                if (code == 3) {
+                    float *acc = a.batch > 1u ? a.planes + (size_t)slot * a.plane_stride : a.image;
+                    float *px = acc + (size_t)pixel * 3;
+                    (void)unsafeAtomicAdd(px, L.x); (void)unsafeAtomicAdd(px + 1, L.y); (void)unsafeAtomicAdd(px + 2, L.z);
+                    emitted++;
                 }
-                nbox += (uint32_t)__popcll(bb);
-                nsph += (uint32_t)__popcll(sb);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+                alive = code <= 2;
             }
         }
 
         // -------------------------------------------------------------------- survivors -> the wave's output stream
-        if (act != 0) {
-            const u64 ballot = __ballot(alive);
-            const uint32_t na = (uint32_t)__popcll(ballot);
-            if (!LAST && na) {
-                if (alive) {
-                    uint32_t p = ofill + wave_rank(ballot);
-                    const uint32_t sg = p >= S ? oseg + nslots : oseg;
-                    p = p >= S ? p - S : p;
-                    const uint32_t oi = sg * S + p;
-                    __builtin_assume(oi < (1u << 29));
-                    float *out = a.out;
-                    out[oi] = o.x; (out + cap)[oi] = o.y; (out + 2 * cap)[oi] = o.z;
-                    (out + 3 * cap)[oi] = d.x; (out + 4 * cap)[oi] = d.y; (out + 5 * cap)[oi] = d.z;
-                    (out + 6 * cap)[oi] = thr.x; (out + 7 * cap)[oi] = thr.y; (out + 8 * cap)[oi] = thr.z;
-                    reinterpret_cast<uint32_t *>(out + 9 * cap)[oi] = pv;
-                }
-                ofill += na;
-                if (ofill >= S) {
-                    if (lane == 0) a.cnt_out[oseg] = S;
-                    oseg += nslots;
-                    ofill -= S;
-                }
+        PT_MARK("out_begin");
+        const u64 ballot = __ballot(alive);
+        const uint32_t na = (uint32_t)__popcll(ballot);
+        if (!LAST && na) {
+            if (alive) {
+                uint32_t p = ofill + wave_rank(ballot);
+                const uint32_t sg = p >= S ? oseg + nslots : oseg;
+                p = p >= S ? p - S : p;
+                const uint32_t oi = sg * S + p;
+                __builtin_assume(oi < (1u << 29));
+                float *out = a.out;
+                out[oi] = o.x; (out + cap)[oi] = o.y; (out + 2 * cap)[oi] = o.z;
+                (out + 3 * cap)[oi] = d.x; (out + 4 * cap)[oi] = d.y; (out + 5 * cap)[oi] = d.z;
+                (out + 6 * cap)[oi] = thr.x; (out + 7 * cap)[oi] = thr.y; (out + 8 * cap)[oi] = thr.z;
+                reinterpret_cast<uint32_t *>(out + 9 * cap)[oi] = pv;
             }
-            survivors += na;
+            ofill += na;
+            if (ofill >= S) {
+                if (lane == 0) a.cnt_out[oseg] = S;
+                oseg += nslots;
+                ofill -= S;
+            }
         }
+        survivors += na;
+        PT_MARK("loop_end");
     }
     // close the output stream: the partly filled segment, then zeros for the wave's unused ones
     if (!LAST && lane == 0) {
@@ -1866,6 +1894,8 @@ struct pt_context {
     bool defer = false;              // sparse-work queue kernel (cfg.ordering == 3: round 1's ring of complex rays; LDS geometry, G <= 32)
     bool queue = false;              // typed work-queue kernel (cfg.ordering == 1; LDS geometry, G <= 32, no merging)
     FaceFrame *d_frames = nullptr;   // [G][3] shading frames of the box primitives (k_bounce_q)
+    CullRec *d_cull = nullptr;       // bounds for its culling pass, cubes first
+    int q_nbox = 0, q_nsph = 0;
     bool binned = false;             // two-ended binned compaction (cfg.ordering == 2; LDS geometry, G <= 32)
     bool use_bvh = false;            // candidate-list kernel (cfg.bvh 1 = BVH walk, 2 = uniform scan; <= 256 primitives)
     BvhNode *d_nodes = nullptr; BoundRec *d_bounds = nullptr; unsigned char *d_order = nullptr;
@@ -1959,6 +1989,8 @@ void free_scene_buffers(pt_context *c) {
     c->d_lights = nullptr;
     if (c->d_frames) (void)hipFree(c->d_frames);
     c->d_frames = nullptr;
+    if (c->d_cull) (void)hipFree(c->d_cull);
+    c->d_cull = nullptr;
     if (c->d_nodes) (void)hipFree(c->d_nodes);
     if (c->d_bounds) (void)hipFree(c->d_bounds);
     if (c->d_order) (void)hipFree(c->d_order);
@@ -2135,8 +2167,10 @@ int launch_defer_t(pt_context *c, const SegArgs &a) {
 
 template <bool LAST, bool GEN>
 int launch_q_t(pt_context *c, const SegArgs &a) {
+    QTables qt;
+    qt.frames = c->d_frames; qt.cull = c->d_cull; qt.nbox = c->q_nbox; qt.nsph = c->q_nsph;
     hipLaunchKernelGGL((k_bounce_q<LAST, GEN>), dim3(c->grid_bounce), dim3(kBlock), c->lds_bytes, c->stream, a,
-                       (const GeomRec *)c->d_geoms, (const MatRec *)c->d_mats, (const FaceFrame *)c->d_frames);
+                       (const GeomRec *)c->d_geoms, (const MatRec *)c->d_mats, qt);
     HIPCHK(hipGetLastError());
     return PT_OK;
 }
@@ -2477,7 +2511,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     // LDS budget: tables (+ the ray stage of the look-back variant)
     uint32_t tb = tables_bytes(G, M, c->geom_lds);
     const uint32_t stage_bytes = c->seg_mode ? (c->defer ? kWaves * kQueueCap * kQueueFields * (uint32_t)sizeof(float)
-                                                : c->queue ? (uint32_t)G * 3u * (uint32_t)sizeof(FaceFrame) + kWaves * kQCap * kQFields * (uint32_t)sizeof(float) : 0u)
+                                                : c->queue ? q_lds_offset(G, M) - tables_bytes(G, M, true) + kWaves * kQCap * kQFields * (uint32_t)sizeof(float) : 0u)
                                              : kBlock * c->rpt * kFields * (uint32_t)sizeof(float);
     if (c->geom_lds && tb + stage_bytes > 160u * 1024u) {   // table too large for LDS: scalar-load path
         if (c->nee) { pth::set_error("pt_upload_scene: direct_light needs the geometry table in LDS (%d primitives do not fit)", G); return PT_ERR_ARGUMENT; }
@@ -2603,6 +2637,28 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
                 for (int col = 0; col < 3; ++col) make_face_frame(g[i].xf, col, &fr[(size_t)i * 3 + col]);
         HIPCHK(hipMalloc(&c->d_frames, fr.size() * sizeof(FaceFrame)));
         HIPCHK(hipMemcpy(c->d_frames, fr.data(), fr.size() * sizeof(FaceFrame), hipMemcpyHostToDevice));
+        // the culling pass's bounds, cubes first (MESH primitives have no entry: the empty branch of the reference)
+        std::vector<CullRec> cr;
+        auto bits = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+        for (int pass = 1; pass >= 0; --pass)
+            for (int i = 0; i < G; ++i) {
+                if (g[i].type != pass) continue;
+                CullRec r;
+                memset(&r, 0, sizeof r);
+                if (pass == 1) {
+                    for (int k = 0; k < 3; ++k) { r.a[k] = g[i].bmin[k]; r.b[k] = g[i].bmax[k]; }
+                    r.a[3] = bits((uint32_t)i); r.b[3] = bits(1u << i);
+                } else {
+                    for (int k = 0; k < 4; ++k) r.a[k] = g[i].bmin[k];
+                    r.b[0] = bits((uint32_t)i); r.b[1] = bits(1u << i); r.b[3] = g[i].bmax[3];
+                }
+                cr.push_back(r);
+            }
+        c->q_nbox = 0; c->q_nsph = 0;
+        for (int i = 0; i < G; ++i) { if (g[i].type == 1) c->q_nbox++; else if (g[i].type == 0) c->q_nsph++; }
+        if (cr.empty()) cr.emplace_back();
+        HIPCHK(hipMalloc(&c->d_cull, cr.size() * sizeof(CullRec)));
+        HIPCHK(hipMemcpy(c->d_cull, cr.data(), cr.size() * sizeof(CullRec), hipMemcpyHostToDevice));
     }
     pth::camera_basis(cam, &c->cfg, &c->cam);
     c->scene_ready = true;
@@ -2756,8 +2812,8 @@ int pt_display(pt_context *c, float scale, void *out, int out_is_device) {
 }
 
 #ifdef PT_CULL_STATS
-int pt_debug_cull_stats(unsigned long long *out8) {
-    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_cull_stats), 64) == hipSuccess ? 0 : -2;
+int pt_debug_cull_stats(unsigned long long *out16) {
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_cull_stats), 128) == hipSuccess ? 0 : -2;
 }
 #endif
 
