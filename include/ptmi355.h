@@ -28,8 +28,9 @@ extern "C" {
 
 /* 2: pt_config grew by `streams` + reserved[3] (1 ended at `direct_light`); always fill pt_config through
  * pt_config_default() first, so that fields added later keep their defaults
- * 3: + pt_get_rows, pt_gather_rows_peer (the per-frame exchange of a row-sharded render) */
-#define PTMI355_ABI_VERSION 3
+ * 3: + pt_get_rows, pt_gather_rows_peer (the per-frame exchange of a row-sharded render)
+ * 4: + pt_mesh, pt_set_meshes, pt_scene_mesh_count, pt_scene_mesh (GEOMTYPE MESH) */
+#define PTMI355_ABI_VERSION 4
 
 typedef enum {
     PT_OK = 0,
@@ -158,6 +159,23 @@ int         pt_device_count(void);               /* HIP devices visible (0 witho
 int  pt_create(const pt_config *cfg, pt_context **out);
 void pt_destroy(pt_context *ctx);
 
+/* Triangle data of a MESH primitive (GEOMTYPE 2, src/sceneStructs.h:14).  The reference tags `*.obj` objects in its
+ * parser (src/scene.cpp:55-64) but neither loads the file nor intersects the type (src/raytraceKernel.cu:144-145 is
+ * empty) and `geom` has no field for the data, so this has no counterpart in cudaRaytraceCore's arguments: callers
+ * with meshes (the library's own loader, ptrender) register them here.  Object space; indices 0-based. */
+typedef struct {
+    int          geom_index;       /* index into the pt_geom array of pt_upload_scene; that geom must have type 2 */
+    const float *vertices;         /* nvertices x 3 */
+    int          nvertices;
+    const int   *indices;          /* ntriangles x 3 */
+    int          ntriangles;
+} pt_mesh;
+/* Copies the meshes; they take effect at the next pt_upload_scene (which builds one BVH per mesh).  nmeshes = 0
+ * clears.  A type-2 geom without a registered mesh is skipped, like every MESH in the reference.  Meshes render on
+ * the stable kernels (ordering / bvh options are ignored for such scenes); direct_light with an emitting mesh is
+ * refused. */
+int  pt_set_meshes(pt_context *ctx, const pt_mesh *meshes, int nmeshes);
+
 /* Scene for one frame == the packing cudaRaytraceCore does at src/raytraceKernel.cu:179-206.
  * Copies; the caller keeps ownership.  (Re)allocates the ray pool for the resolution. */
 int  pt_upload_scene(pt_context *ctx, const pt_geom *geoms, int ngeoms,
@@ -227,6 +245,11 @@ int  pt_scene_counts(const pt_scene *s, int *ngeoms, int *nmaterials, int *nfram
 const char *pt_scene_image_name(const pt_scene *s);
 /* flatten frame `frame` the way cudaRaytraceCore does; arrays sized by pt_scene_counts */
 int  pt_scene_flatten(const pt_scene *s, int frame, pt_geom *geoms, pt_material *materials, pt_camera *camera);
+/* MESH objects of the file: the `<name>.obj` named on the object's type line is read relative to the scene file
+ * (`v x y z` and `f a b c ...` lines; polygons are fanned; a/b/c index forms and negative indices accepted).
+ * pt_scene_mesh fills *mesh with pointers owned by the scene (valid until pt_scene_free). */
+int  pt_scene_mesh_count(const pt_scene *s);
+int  pt_scene_mesh(const pt_scene *s, int k, pt_mesh *mesh);
 /* full 4x4 rows of transform / inverse of object i at frame f (parity with scene.cpp:123-125) */
 int  pt_scene_object_matrices(const pt_scene *s, int object, int frame, float transform16[16], float inverse16[16]);
 /* buildTransformationMatrix + inverse (src/utilities.cpp:70-86) */

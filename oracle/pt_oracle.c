@@ -284,6 +284,90 @@ float orc_box_test(const orc_geom *g, int inside_hits, const float o[3], const f
     return vlength(vsub(ip, O));
 }
 
+/* ------------------------------------------------------------------ MESH (build-defined) - */
+/* The reference declares GEOMTYPE MESH (src/sceneStructs.h:14), tags `*.obj` objects in the parser
+ * (src/scene.cpp:55-64) and leaves the kernel branch empty (src/raytraceKernel.cu:144-145).  The build's
+ * definition, restated here as a brute-force loop over the triangles in file order:
+ *   object-space ray as in the sphere test (:171-172): ro = M^-1 (o,1), rd = normalize(M^-1 (d,0));
+ *   per triangle (v0, e1 = v1-v0, e2 = v2-v0): two-sided Moeller-Trumbore with this exact expression order;
+ *   nearest t > 0 wins, a tie goes to the earlier triangle;
+ *   hit point like getPointOnRay (:46-48) without its second normalize: P = M (ro + float(t-.0001) rd, 1);
+ *   normal = normalize((M^-1)^T (e1 x e2)); returned depth = |o - P| in world space like the other tests. */
+typedef struct {
+    int geom_index;
+    const float *vertices;      /* nvertices x 3, object space */
+    int nvertices;
+    const int *indices;         /* ntriangles x 3 */
+    int ntriangles;
+} orc_mesh_rec;
+
+static orc_mesh_rec g_meshes[64];
+static int g_nmeshes = 0;
+
+/* Registers the meshes of the scene about to be rendered (pointers are kept, not copied); n = 0 clears.
+ * A MESH primitive without a registered mesh is skipped like in the reference. */
+int orc_set_meshes(const int *geom_index, const float *const *vertices, const int *nvertices,
+                   const int *const *indices, const int *ntriangles, int n) {
+    if (n < 0 || n > 64) return -1;
+    for (int i = 0; i < n; i++) {
+        g_meshes[i].geom_index = geom_index[i];
+        g_meshes[i].vertices = vertices[i]; g_meshes[i].nvertices = nvertices[i];
+        g_meshes[i].indices = indices[i]; g_meshes[i].ntriangles = ntriangles[i];
+    }
+    g_nmeshes = n;
+    return 0;
+}
+
+/* one triangle; returns t (object space) or -1 */
+float orc_triangle_test(const float v0a[3], const float e1a[3], const float e2a[3], const float roa[3], const float rda[3]) {
+    v3 v0 = vload(v0a), e1 = vload(e1a), e2 = vload(e2a), ro = vload(roa), rd = vload(rda);
+    v3 pvec = vcross(rd, e2);
+    float det = vdot(e1, pvec);
+    if (det == 0.0f) return -1.0f;
+    float inv_det = 1.0f / det;
+    v3 tvec = vsub(ro, v0);
+    float u = vdot(tvec, pvec) * inv_det;
+    if (u < 0.0f || u > 1.0f) return -1.0f;
+    v3 qvec = vcross(tvec, e1);
+    float v = vdot(rd, qvec) * inv_det;
+    if (v < 0.0f || u + v > 1.0f) return -1.0f;
+    float t = vdot(e2, qvec) * inv_det;
+    if (!(t > 0.0f)) return -1.0f;
+    return t;
+}
+
+float orc_mesh_test(const orc_geom *g, const float *vertices, const int *indices, int ntriangles,
+                    const float o[3], const float d[3], float P[3], float N[3], int *triangle) {
+    v3 ro = mulmv(g->inverseTransform, vload(o), 1.0f);
+    v3 rd = vnormalize(mulmv(g->inverseTransform, vload(d), 0.0f));
+    float roa[3], rda[3];
+    vstore(roa, ro); vstore(rda, rd);
+    float best = -1.0f;
+    int win = -1;
+    v3 wng = V(0.0f, 0.0f, 0.0f);
+    for (int k = 0; k < ntriangles; k++) {
+        v3 v0 = vload(vertices + 3 * indices[3 * k]);
+        v3 e1 = vsub(vload(vertices + 3 * indices[3 * k + 1]), v0);
+        v3 e2 = vsub(vload(vertices + 3 * indices[3 * k + 2]), v0);
+        float v0a[3], e1a[3], e2a[3];
+        vstore(v0a, v0); vstore(e1a, e1); vstore(e2a, e2);
+        float t = orc_triangle_test(v0a, e1a, e2a, roa, rda);
+        if (t > 0.0f && (win < 0 || t < best)) { best = t; win = k; wng = vcross(e1, e2); }
+    }
+    if (triangle) *triangle = win;
+    if (win < 0) return -1.0f;
+    float tt = (float)((double)best - .0001);
+    v3 pobj = vadd(ro, vscale(rd, tt));
+    v3 wp = mulmv(g->transform, pobj, 1.0f);
+    const float *m = g->inverseTransform;
+    v3 n = V((m[0] * wng.x + m[4] * wng.y) + m[8] * wng.z,
+             (m[1] * wng.x + m[5] * wng.y) + m[9] * wng.z,
+             (m[2] * wng.x + m[6] * wng.y) + m[10] * wng.z);
+    vstore(P, wp);
+    vstore(N, vnormalize(n));
+    return vlength(vsub(vload(o), wp));
+}
+
 /* geometry loop of raytraceRay (src/raytraceKernel.cu:134-153): first strictly nearer wins */
 int orc_nearest_hit(const orc_geom *geoms, int ngeoms, const orc_material *mats,
                     const float o[3], const float d[3], float *t, float P[3], float N[3]) {
@@ -295,7 +379,14 @@ int orc_nearest_hit(const orc_geom *geoms, int ngeoms, const orc_material *mats,
         else if (geoms[i].type == 1) {
             int inside = mats ? (mats[geoms[i].materialid].hasRefractive > 0.0f) : 0;
             depth = orc_box_test(&geoms[i], inside, o, d, p, n);
-        } else continue;                      /* MESH: empty branch in the reference (:144-145) */
+        } else {
+            /* MESH: empty branch in the reference (:144-145); the build's definition when a mesh is registered */
+            const orc_mesh_rec *mr = NULL;
+            for (int k = 0; k < g_nmeshes; k++)
+                if (g_meshes[k].geom_index == i) mr = &g_meshes[k];
+            if (!mr || geoms[i].type != 2) continue;
+            depth = orc_mesh_test(&geoms[i], mr->vertices, mr->indices, mr->ntriangles, o, d, p, n, NULL);
+        }
         if (depth < MAX_DEPTH && depth > -ORC_EPSILON) {
             MAX_DEPTH = depth;
             hit = i;

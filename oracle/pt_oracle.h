@@ -135,6 +135,12 @@ float orc_sphere_test_powdouble(const orc_geom *g, const float o[3], const float
 void orc_point_on_ray(const float o[3], const float d[3], float t, float out[3]);
 float orc_box_test(const orc_geom *g, int inside_hits, const float o[3], const float d[3],
                    float P[3], float N[3]);
+/* MESH primitives (the reference only declares the type): DESIGN.md section 3.8 */
+int   orc_set_meshes(const int *geom_index, const float *const *vertices, const int *nvertices,
+                     const int *const *indices, const int *ntriangles, int n);
+float orc_triangle_test(const float v0[3], const float e1[3], const float e2[3], const float ro[3], const float rd[3]);
+float orc_mesh_test(const orc_geom *g, const float *vertices, const int *indices, int ntriangles,
+                    const float o[3], const float d[3], float P[3], float N[3], int *triangle);
 int   orc_nearest_hit(const orc_geom *geoms, int ngeoms, const orc_material *mats,
                       const float o[3], const float d[3], float *t, float P[3], float N[3]);
 

@@ -50,6 +50,11 @@ class Config(C.Structure):     # == pt_config
                 ("compaction", C.c_int), ("culling", C.c_int), ("merge_floor", C.c_int), ("batch", C.c_int), ("ordering", C.c_int), ("bvh", C.c_int), ("direct_light", C.c_int), ("streams", C.c_int), ("reserved", C.c_int * 3)]
 
 
+class Mesh(C.Structure):       # == pt_mesh
+    _fields_ = [("geom_index", C.c_int), ("vertices", C.POINTER(C.c_float)), ("nvertices", C.c_int),
+                ("indices", C.POINTER(C.c_int)), ("ntriangles", C.c_int)]
+
+
 class Stats(C.Structure):      # == pt_stats
     _fields_ = [("generate_ms", C.c_double), ("bounce_ms", C.c_double), ("display_ms", C.c_double),
                 ("generate_launches", C.c_uint64), ("bounce_launches", C.c_uint64),
@@ -81,6 +86,9 @@ def lib():
     L.pt_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
     L.pt_destroy.argtypes = [vp]; L.pt_destroy.restype = None
     L.pt_upload_scene.argtypes = [vp, C.POINTER(Geom), C.c_int, C.POINTER(Material), C.c_int, C.POINTER(Camera)]
+    L.pt_set_meshes.argtypes = [vp, C.POINTER(Mesh), C.c_int]
+    L.pt_scene_mesh_count.argtypes = [vp]
+    L.pt_scene_mesh.argtypes = [vp, C.c_int, C.POINTER(Mesh)]
     L.pt_set_image.argtypes = [vp, fp]
     L.pt_bind_device_image.argtypes = [vp, vp]
     L.pt_get_image.argtypes = [vp, fp]
@@ -114,7 +122,7 @@ def lib():
 
 EXPORTS = [
     "pt_abi_version", "pt_last_error", "pt_config_default", "pt_device_count", "pt_create", "pt_destroy",
-    "pt_upload_scene", "pt_set_image", "pt_bind_device_image", "pt_get_image", "pt_get_rows", "pt_gather_rows_peer", "pt_render", "pt_sync",
+    "pt_upload_scene", "pt_set_meshes", "pt_scene_mesh_count", "pt_scene_mesh", "pt_set_image", "pt_bind_device_image", "pt_get_image", "pt_get_rows", "pt_gather_rows_peer", "pt_render", "pt_sync",
     "pt_display", "pt_set_profiling", "pt_get_stats", "pt_reset_stats", "pt_get_resolution", "pt_debug_primary_hits",
     "pt_debug_trace_pool", "pt_debug_rng_from_thread", "pt_debug_hemisphere", "pt_debug_sincos", "pt_debug_light_points",
     "pt_scene_load", "pt_scene_free", "pt_scene_counts", "pt_scene_image_name", "pt_scene_flatten",
@@ -157,6 +165,17 @@ class SceneFile:
         _check(lib().pt_scene_flatten(self._h, frame, geoms, mats, C.byref(cam)))
         return geoms, mats, cam
 
+    def meshes(self):
+        """[(geom_index, vertices float32 [n,3], indices int32 [t,3])] of the MESH objects whose .obj was found"""
+        out = []
+        for k in range(lib().pt_scene_mesh_count(self._h)):
+            m = Mesh()
+            _check(lib().pt_scene_mesh(self._h, k, C.byref(m)))
+            v = np.ctypeslib.as_array(m.vertices, shape=(m.nvertices, 3)).astype(np.float32).copy()
+            i = np.ctypeslib.as_array(m.indices, shape=(m.ntriangles, 3)).astype(np.int32).copy()
+            out.append((m.geom_index, v, i))
+        return out
+
     def object_matrices(self, obj, frame=0):
         xf, inv = np.zeros(16, np.float32), np.zeros(16, np.float32)
         _check(lib().pt_scene_object_matrices(self._h, obj, frame, _fp(xf), _fp(inv)))
@@ -183,6 +202,18 @@ class PathTracer:
         _check(lib().pt_create(C.byref(self.cfg), C.byref(self._h)))
         self.W = self.H = self.owned = 0
         self._bound = None
+
+    def set_meshes(self, meshes):
+        """meshes: [(geom_index, vertices [n,3] float32, indices [t,3] int32)]; used by the next upload()"""
+        arr = (Mesh * max(1, len(meshes)))()
+        keep = []
+        for k, (gi, v, i) in enumerate(meshes):
+            v = np.ascontiguousarray(v, np.float32); i = np.ascontiguousarray(i, np.int32)
+            keep += [v, i]
+            arr[k].geom_index = int(gi)
+            arr[k].vertices = v.ctypes.data_as(C.POINTER(C.c_float)); arr[k].nvertices = len(v)
+            arr[k].indices = i.ctypes.data_as(C.POINTER(C.c_int)); arr[k].ntriangles = len(i)
+        _check(lib().pt_set_meshes(self._h, arr, len(meshes)))
 
     def upload(self, geoms, mats, cam):
         _check(lib().pt_upload_scene(self._h, geoms, len(geoms), mats, len(mats), C.byref(cam)))

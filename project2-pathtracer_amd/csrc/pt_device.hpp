@@ -216,6 +216,52 @@ PTD_FN float box_test(const float *inv, const float *xf, int inside_hits, f3 o, 
     return depth;
 }
 
+// ---------------------------------------------------------------- MESH (build-defined) --
+// The reference declares GEOMTYPE MESH and leaves its kernel branch empty (src/raytraceKernel.cu:144-145); the
+// build's definition is DESIGN.md section 3.8 (oracle: orc_triangle_test / orc_mesh_test).  One triangle as the
+// kernels read it: v0, the two edges, the object-space geometric normal e1 x e2 (all evaluated by the host with
+// the functions of this header) and the triangle's index in the file (ties go to the earlier triangle): 64 bytes.
+struct __attribute__((aligned(16))) MeshTri {
+    float v0[3]; int index;
+    float e1[3]; float pad1;
+    float e2[3]; float pad2;
+    float ng[3]; float pad3;
+};
+// threaded BVH node (depth-first order): on a miss, or after a leaf, traversal continues at `skip` (-1 = done); an
+// inner node's first child is the next node.  leaf < 0: inner; else first triangle | count << 27.  32 bytes.
+struct __attribute__((aligned(16))) MeshNode {
+    float bmin[3]; int skip;
+    float bmax[3]; int leaf;
+};
+
+// two-sided Moeller-Trumbore in this exact expression order; returns t > 0 or -1
+PTD_FN float triangle_test(f3 v0, f3 e1, f3 e2, f3 ro, f3 rd) {
+    const f3 pvec = cross(rd, e2);
+    const float det = dot(e1, pvec);
+    if (det == 0.0f) return -1.0f;
+    const float inv_det = 1.0f / det;
+    const f3 tvec = ro - v0;
+    const float u = dot(tvec, pvec) * inv_det;
+    if (u < 0.0f || u > 1.0f) return -1.0f;
+    const f3 qvec = cross(tvec, e1);
+    const float v = dot(rd, qvec) * inv_det;
+    if (v < 0.0f || u + v > 1.0f) return -1.0f;
+    const float t = dot(e2, qvec) * inv_det;
+    if (!(t > 0.0f)) return -1.0f;
+    return t;
+}
+// hit point and normal of the winning triangle (object-space t, geometric normal ng)
+PTD_FN float mesh_finish(const float *inv, const float *xf, f3 o, f3 ro, f3 rd, float t, f3 ng, f3 &P, f3 &N) {
+    const float tt = (float)((double)t - .0001);
+    const f3 wp = mul_point(xf, ro + rd * tt);
+    const f3 n = mk((inv[0] * ng.x + inv[4] * ng.y) + inv[8] * ng.z,
+                    (inv[1] * ng.x + inv[5] * ng.y) + inv[9] * ng.z,
+                    (inv[2] * ng.x + inv[6] * ng.y) + inv[10] * ng.z);
+    P = wp;
+    N = normalize(n);
+    return length(o - wp);
+}
+
 // ---------------------------------------------------------------- light sampling -------
 // getRadiuses / getRandomPointOnCube / getRandomPointOnSphere (src/intersections.h:207-286): no
 // call sites in the reference; provided (and parity-tested against the oracle) for next-event

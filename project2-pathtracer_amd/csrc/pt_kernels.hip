@@ -88,6 +88,8 @@ struct BounceArgs {
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
+__device__ __forceinline__ float mesh_test(const GeomRec *g, f3 o, f3 d, f3 &P, f3 &N);
+
 // ------------------------------------------------------------------ nearest hit --------
 // geometry loop of raytraceRay (src/raytraceKernel.cu:134-153)
 template <typename GeomPtr>
@@ -100,7 +102,8 @@ __device__ __forceinline__ int nearest_hit(GeomPtr geoms, int G, f3 o, f3 d, flo
         const int type = geoms[i].type;
         if (type == 0) depth = sphere_test(geoms[i].inv, geoms[i].xf, o, d, p, n);
         else if (type == 1) depth = box_test(geoms[i].inv, geoms[i].xf, geoms[i].inside_hits, o, d, p, n);
-        else continue;
+        else if (type == 2 && geoms[i].inside_hits != 0) depth = mesh_test(&geoms[i], o, d, p, n);   // a registered mesh
+        else continue;                                    // MESH without data: the reference's empty branch
         if (depth < maxd && depth > -PT_EPSILON) { maxd = depth; hit = i; P = p; N = n; }
     }
     tbest = maxd;
@@ -163,6 +166,48 @@ __device__ __forceinline__ bool cull_sphere(const float *bmin, const float *bmax
     return !((perp2 > lim) || (b < 0.0f && c2 > lim));
 }
 
+// ------------------------------------------------------------------ MESH primitive --------------
+// Exact test of a MESH primitive: the nearest triangle by object-space t, ties to the earlier
+// triangle -- the oracle's brute-force loop -- found through the mesh's threaded BVH.  The slab tests are cull-side
+// arithmetic (FMAs, approximate reciprocals, margins on both sides, boxes inflated by the host); a node is skipped
+// only if it is entered beyond the best hit so far.  Per-lane traversal: no stack, one node index per lane.
+// A mesh's GeomRec carries the address of its blob [MeshNode x nnodes | MeshTri x ntris] in bmin[3] / bmax[3] and the
+// byte offset of the triangles in inside_hits.
+__device__ __forceinline__ float mesh_test(const GeomRec *g, f3 o, f3 d, f3 &P, f3 &N) {
+    const float *inv = g->inv, *xf = g->xf;
+    const unsigned long long base = ((unsigned long long)__float_as_uint(g->bmax[3]) << 32) | (unsigned long long)__float_as_uint(g->bmin[3]);
+    const MeshNode *nodes = reinterpret_cast<const MeshNode *>(base);
+    const MeshTri *tris = reinterpret_cast<const MeshTri *>(base + (unsigned long long)(uint32_t)g->inside_hits);
+    const f3 ro = mul_point(inv, o);
+    const f3 rd = normalize(mul_vector(inv, d));
+    const CullRay cr = make_cull_ray(ro, rd);
+    float best = 3.0e38f;
+    int win = -1, widx = 0x7FFFFFFF;
+    int node = 0;
+    while (node >= 0) {
+        const float4 lo = *reinterpret_cast<const float4 *>(nodes[node].bmin);      // bmin.xyz, skip
+        const float4 hi = *reinterpret_cast<const float4 *>(nodes[node].bmax);      // bmax.xyz, leaf
+        const float bl[3] = {lo.x, lo.y, lo.z}, bh[3] = {hi.x, hi.y, hi.z};
+        float tn;
+        const bool in = cull_box(bl, bh, cr, tn) && !(tn > best);
+        const int skip = __float_as_int(lo.w), leaf = __float_as_int(hi.w);
+        if (!in) { node = skip; continue; }
+        if (leaf < 0) { node = node + 1; continue; }
+        const int first = leaf & 0x7FFFFFF, cnt = (int)((uint32_t)leaf >> 27);
+        for (int k = 0; k < cnt; ++k) {
+            const float4 *tp = reinterpret_cast<const float4 *>(tris + first + k);
+            const float4 a = tp[0], b = tp[1], c = tp[2];
+            const float t = triangle_test(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), ro, rd);
+            const int idx = __float_as_int(a.w);
+            if (t > 0.0f && (t < best || (t == best && idx < widx))) { best = t; win = first + k; widx = idx; }
+        }
+        node = skip;
+    }
+    if (win < 0) return -1.0f;
+    const float4 ngv = reinterpret_cast<const float4 *>(tris + win)[3];
+    return mesh_finish(inv, xf, o, ro, rd, best, mk(ngv.x, ngv.y, ngv.z), P, N);
+}
+
 #ifdef PT_CULL_STATS
 __device__ unsigned long long g_cull_stats[16];  // [8..15] typed-queue kernel: fresh groups, fresh valid lanes, box groups, box lanes, sphere groups, sphere lanes, shaded lanes, re-queued lanes
 __device__ __forceinline__ void qstat(int i, unsigned long long v) { if ((threadIdx.x & 63) == 0 && v) atomicAdd(&g_cull_stats[i], v); }
@@ -178,22 +223,23 @@ __device__ __forceinline__ int nearest_hit_culled(const GeomRec *lg, const GeomR
     int hit = -1;
     for (int base = 0; base < G; base += 32) {
         const int n = (G - base) < 32 ? (G - base) : 32;
-        uint32_t mask = 0u, boxbits = 0u, sphbits = 0u;
+        uint32_t mask = 0u, boxbits = 0u, sphbits = 0u, meshbits = 0u;
         // nearest candidate (smallest conservative entry distance) per type: tested first, so that its
         // exact hit lets the cheap re-check below drop the lane's other candidates
-        float near_t[2] = {3.0e38f, 3.0e38f};
-        int near_j[2] = {-1, -1};
+        float near_t[3] = {3.0e38f, 3.0e38f, 3.0e38f};
+        int near_j[3] = {-1, -1, -1};
         for (int j = 0; j < n; ++j) {                     // wave-uniform index: broadcast / scalar loads
             const GeomRec &g = tab[base + j];
             const int type = g.type;
             float tn;
             bool keep;
-            if (type == 1) { boxbits |= 1u << j; keep = cull_box(g.bmin, g.bmax, cr, tn); }
-            else if (type == 0) { sphbits |= 1u << j; keep = cull_sphere(g.bmin, g.bmax, cr, tn); }
-            else continue;                                // MESH: empty branch in the reference
+            int ty;
+            if (type == 1) { boxbits |= 1u << j; keep = cull_box(g.bmin, g.bmax, cr, tn); ty = 0; }
+            else if (type == 0) { sphbits |= 1u << j; keep = cull_sphere(g.bmin, g.bmax, cr, tn); ty = 1; }
+            else if (type == 2 && g.inside_hits != 0) { meshbits |= 1u << j; keep = cull_box(g.bmin, g.bmax, cr, tn); ty = 2; }
+            else continue;                                // MESH without data: empty branch in the reference
             if (keep) {
                 mask |= 1u << j;
-                const int ty = type == 1 ? 0 : 1;
                 if (tn < near_t[ty]) { near_t[ty] = tn; near_j[ty] = j; }
             }
         }
@@ -201,12 +247,13 @@ __device__ __forceinline__ int nearest_hit_culled(const GeomRec *lg, const GeomR
         if ((threadIdx.x & 63) == 0) atomicAdd(&g_cull_stats[0], 1ull);
         atomicAdd(&g_cull_stats[5], (unsigned long long)__popc(mask));
 #endif
-        for (int pass = 0; pass < 2; ++pass) {
-            uint32_t m = mask & (pass == 0 ? boxbits : sphbits);
+        for (int pass = 0; pass < 3; ++pass) {
+            if (pass == 2 && meshbits == 0u) break;       // wave-uniform: scenes without meshes never enter the pass
+            uint32_t m = mask & (pass == 0 ? boxbits : pass == 1 ? sphbits : meshbits);
             bool first = true;
             while (m) {                                   // per-lane loop; the wave runs until all lanes are done
 #ifdef PT_CULL_STATS
-                {
+                if (pass < 2) {
                     const unsigned long long act = __ballot(1);
                     if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(act)) {
                         atomicAdd(&g_cull_stats[1 + 2 * pass], 1ull);
@@ -220,13 +267,15 @@ __device__ __forceinline__ int nearest_hit_culled(const GeomRec *lg, const GeomR
                 const GeomRec *g = tab + base + j;        // per-lane gather
                 if (hit >= 0) {                           // entered farther than the best exact hit: cannot win or tie
                     float tn;
-                    if (pass == 0) (void)cull_box(g->bmin, g->bmax, cr, tn);
+                    if (pass != 1) (void)cull_box(g->bmin, g->bmax, cr, tn);
                     else (void)cull_sphere(g->bmin, g->bmax, cr, tn);
                     if (tn - g->slack > best) continue;
                 }
                 f3 p, nn;
-                const float depth = pass == 0 ? box_test(g->inv, g->xf, g->inside_hits, o, d, p, nn)
-                                              : sphere_test(g->inv, g->xf, o, d, p, nn);
+                float depth;
+                if (pass == 0) depth = box_test(g->inv, g->xf, g->inside_hits, o, d, p, nn);
+                else if (pass == 1) depth = sphere_test(g->inv, g->xf, o, d, p, nn);
+                else depth = mesh_test(g, o, d, p, nn);
                 const int idx = base + j;
                 if (depth > -PT_EPSILON && (depth < best || (depth == best && idx < hit))) {
                     best = depth; hit = idx; P = p; N = nn;
@@ -1896,6 +1945,10 @@ struct pt_context {
     FaceFrame *d_frames = nullptr;   // [G][3] shading frames of the box primitives (k_bounce_q)
     CullRec *d_cull = nullptr;       // bounds for its culling pass, cubes first
     int q_nbox = 0, q_nsph = 0;
+    // MESH primitives (pt_set_meshes): host copies, and one device blob [nodes | triangles] per mesh of the uploaded scene
+    struct HostMesh { int geom_index; std::vector<float> v; std::vector<int> idx; };
+    std::vector<HostMesh> meshes;
+    std::vector<void *> d_mesh_blobs;
     bool binned = false;             // two-ended binned compaction (cfg.ordering == 2; LDS geometry, G <= 32)
     bool use_bvh = false;            // candidate-list kernel (cfg.bvh 1 = BVH walk, 2 = uniform scan; <= 256 primitives)
     BvhNode *d_nodes = nullptr; BoundRec *d_bounds = nullptr; unsigned char *d_order = nullptr;
@@ -1991,6 +2044,8 @@ void free_scene_buffers(pt_context *c) {
     c->d_frames = nullptr;
     if (c->d_cull) (void)hipFree(c->d_cull);
     c->d_cull = nullptr;
+    for (void *b : c->d_mesh_blobs) (void)hipFree(b);
+    c->d_mesh_blobs.clear();
     if (c->d_nodes) (void)hipFree(c->d_nodes);
     if (c->d_bounds) (void)hipFree(c->d_bounds);
     if (c->d_order) (void)hipFree(c->d_order);
@@ -2093,6 +2148,107 @@ struct BvhBuild {
         return id;
     }
 };
+
+// ---- MESH: threaded BVH over the triangles of one mesh (object space), built at upload ----------------------
+// Median split of the triangle centroids along the widest axis, <= 4 triangles per leaf, nodes in depth-first
+// order with skip links (traversal needs no stack).  Boxes are the exact float min/max of the member vertices,
+// inflated by 1e-5 * (1 + largest |coordinate|): the slab test adds its own relative margins (cull_box).
+struct MeshBuild {
+    const float *v;
+    const int *idx;
+    std::vector<int> order;                  // triangle permutation (leaf ranges index into it)
+    std::vector<MeshNode> nodes;
+    std::vector<float> cen;                  // 3 per triangle
+    void bounds(int first, int count, float lo[3], float hi[3]) const {
+        for (int k = 0; k < 3; ++k) { lo[k] = 3e38f; hi[k] = -3e38f; }
+        for (int i = first; i < first + count; ++i)
+            for (int c = 0; c < 3; ++c) {
+                const float *p = v + 3 * idx[3 * order[i] + c];
+                for (int k = 0; k < 3; ++k) { lo[k] = std::fmin(lo[k], p[k]); hi[k] = std::fmax(hi[k], p[k]); }
+            }
+    }
+    int emit(int first, int count, int parent_skip) {
+        const int id = (int)nodes.size();
+        nodes.emplace_back();
+        float lo[3], hi[3];
+        bounds(first, count, lo, hi);
+        float maxabs = 0.0f;
+        for (int k = 0; k < 3; ++k) maxabs = std::fmax(maxabs, std::fmax(std::fabs(lo[k]), std::fabs(hi[k])));
+        const float infl = 1e-5f * (1.0f + maxabs);
+        for (int k = 0; k < 3; ++k) { nodes[id].bmin[k] = lo[k] - infl; nodes[id].bmax[k] = hi[k] + infl; }
+        nodes[id].skip = parent_skip;
+        if (count <= 4) { nodes[id].leaf = first | (count << 27); return id; }
+        nodes[id].leaf = -1;
+        int axis = 0;
+        float ext = -1.0f;
+        for (int k = 0; k < 3; ++k) {
+            float cmin = 3e38f, cmax = -3e38f;
+            for (int i = first; i < first + count; ++i) { cmin = std::fmin(cmin, cen[3 * order[i] + k]); cmax = std::fmax(cmax, cen[3 * order[i] + k]); }
+            if (cmax - cmin > ext) { ext = cmax - cmin; axis = k; }
+        }
+        const int half = count / 2;
+        std::nth_element(order.begin() + first, order.begin() + first + half, order.begin() + first + count,
+                         [&](int x, int y) { return cen[3 * x + axis] < cen[3 * y + axis] || (cen[3 * x + axis] == cen[3 * y + axis] && x < y); });
+        const int left = emit(first, half, -2);                      // -2: "the right sibling", known once the left subtree is out
+        const int right = emit(first + half, count - half, parent_skip);
+        for (int k = left; k < right; ++k)
+            if (nodes[k].skip == -2) nodes[k].skip = right;
+        return id;
+    }
+};
+
+// [MeshNode x nnodes (padded to a multiple of 2) | MeshTri x ntris] for one mesh; *tri_offset = byte offset of the triangles
+std::vector<unsigned char> build_mesh_blob(const pt_context::HostMesh &hm, uint32_t *tri_offset) {
+    MeshBuild mb;
+    mb.v = hm.v.data(); mb.idx = hm.idx.data();
+    const int nt = (int)(hm.idx.size() / 3);
+    mb.order.resize(nt); mb.cen.resize((size_t)3 * nt);
+    for (int t = 0; t < nt; ++t) {
+        mb.order[t] = t;
+        for (int k = 0; k < 3; ++k)
+            mb.cen[3 * t + k] = (hm.v[3 * hm.idx[3 * t] + k] + hm.v[3 * hm.idx[3 * t + 1] + k] + hm.v[3 * hm.idx[3 * t + 2] + k]) * (1.0f / 3.0f);
+    }
+    mb.emit(0, nt, -1);
+    const size_t nn = (mb.nodes.size() + 1) & ~(size_t)1;
+    *tri_offset = (uint32_t)(nn * sizeof(MeshNode));
+    std::vector<unsigned char> blob(nn * sizeof(MeshNode) + (size_t)nt * sizeof(MeshTri), 0);
+    memcpy(blob.data(), mb.nodes.data(), mb.nodes.size() * sizeof(MeshNode));
+    MeshTri *tris = reinterpret_cast<MeshTri *>(blob.data() + *tri_offset);
+    for (int i = 0; i < nt; ++i) {
+        const int t = mb.order[i];
+        const float *p0 = &hm.v[3 * hm.idx[3 * t]], *p1 = &hm.v[3 * hm.idx[3 * t + 1]], *p2 = &hm.v[3 * hm.idx[3 * t + 2]];
+        const f3 v0 = mk(p0[0], p0[1], p0[2]);
+        const f3 e1 = mk(p1[0], p1[1], p1[2]) - v0, e2 = mk(p2[0], p2[1], p2[2]) - v0;     // the kernels' own float subtraction
+        const f3 ng = cross(e1, e2);
+        MeshTri &r = tris[i];
+        r.v0[0] = v0.x; r.v0[1] = v0.y; r.v0[2] = v0.z; r.index = t;
+        r.e1[0] = e1.x; r.e1[1] = e1.y; r.e1[2] = e1.z;
+        r.e2[0] = e2.x; r.e2[1] = e2.y; r.e2[2] = e2.z;
+        r.ng[0] = ng.x; r.ng[1] = ng.y; r.ng[2] = ng.z;
+    }
+    return blob;
+}
+
+// conservative world-space AABB of a mesh primitive (double precision, inflated like the cubes')
+void mesh_world_bounds(const pt_geom &src, const pt_context::HostMesh &hm, GeomRec *dst) {
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, maxabs = 0.0, maxrow = 0.0;
+    const float *m = src.transform;
+    for (size_t i = 0; i + 2 < hm.v.size(); i += 3)
+        for (int k = 0; k < 3; ++k) {
+            const double w = (double)m[4 * k] * hm.v[i] + (double)m[4 * k + 1] * hm.v[i + 1] + (double)m[4 * k + 2] * hm.v[i + 2] + (double)m[4 * k + 3];
+            lo[k] = std::fmin(lo[k], w); hi[k] = std::fmax(hi[k], w);
+        }
+    for (int k = 0; k < 3; ++k) {
+        maxabs = std::fmax(maxabs, std::fmax(std::fabs(lo[k]), std::fabs(hi[k])));
+        maxrow = std::fmax(maxrow, std::sqrt((double)m[4 * k] * m[4 * k] + (double)m[4 * k + 1] * m[4 * k + 1] + (double)m[4 * k + 2] * m[4 * k + 2]));
+    }
+    const double infl = 3e-5 + 4e-6 * maxabs;
+    for (int k = 0; k < 3; ++k) {
+        dst->bmin[k] = std::nextafterf((float)(lo[k] - infl), -INFINITY);
+        dst->bmax[k] = std::nextafterf((float)(hi[k] + infl), INFINITY);
+    }
+    dst->slack = (float)(1.5e-4 * maxrow + 1e-5);        // the hit point sits 1e-4 (object space) in front of the surface
+}
 
 template <bool LAST, bool GEN>
 int launch_bvh_t(pt_context *c, const SegArgs &a) {
@@ -2392,6 +2548,28 @@ void pt_destroy(pt_context *c) {
     delete c;
 }
 
+int pt_set_meshes(pt_context *c, const pt_mesh *meshes, int nmeshes) {
+    if (!c || nmeshes < 0 || (nmeshes > 0 && !meshes)) { pth::set_error("pt_set_meshes: bad argument"); return PT_ERR_ARGUMENT; }
+    std::vector<pt_context::HostMesh> copy;
+    for (int i = 0; i < nmeshes; ++i) {
+        const pt_mesh &m = meshes[i];
+        if (!m.vertices || !m.indices || m.nvertices < 3 || m.ntriangles < 1 || m.ntriangles >= (1 << 27) || m.geom_index < 0) {
+            pth::set_error("pt_set_meshes: mesh %d is empty or malformed", i);
+            return PT_ERR_ARGUMENT;
+        }
+        for (int k = 0; k < 3 * m.ntriangles; ++k)
+            if (m.indices[k] < 0 || m.indices[k] >= m.nvertices) { pth::set_error("pt_set_meshes: mesh %d: vertex index %d out of range (%d vertices)", i, m.indices[k], m.nvertices); return PT_ERR_ARGUMENT; }
+        pt_context::HostMesh hm;
+        hm.geom_index = m.geom_index;
+        hm.v.assign(m.vertices, m.vertices + (size_t)3 * m.nvertices);
+        hm.idx.assign(m.indices, m.indices + (size_t)3 * m.ntriangles);
+        copy.push_back(std::move(hm));
+    }
+    c->meshes.swap(copy);
+    for (pt_context *s : c->subs) { int rc = pt_set_meshes(s, meshes, nmeshes); if (rc) return rc; }
+    return PT_OK;
+}
+
 int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_material *mats, int M, const pt_camera *cam) {
     if (!c || !geoms || !mats || !cam || G < 1 || M < 1) { pth::set_error("pt_upload_scene: bad argument"); return PT_ERR_ARGUMENT; }
     if (!c->subs.empty()) {
@@ -2436,7 +2614,17 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         g[i].type = geoms[i].type;
         g[i].mat = geoms[i].materialid;
         g[i].inside_hits = mats[geoms[i].materialid].hasRefractive > 0.0f ? 1 : 0;
+        if (geoms[i].type == 2) g[i].inside_hits = 0;     // MESH: byte offset of its triangles, set below when data is registered
         world_bounds(geoms[i], &g[i]);
+    }
+    // MESH primitives with registered data (the others are skipped like the reference's empty branch)
+    std::vector<const pt_context::HostMesh *> mesh_of(G, nullptr);
+    bool have_mesh = false;
+    for (const pt_context::HostMesh &hm : c->meshes) {
+        if (hm.geom_index >= G || geoms[hm.geom_index].type != 2) { pth::set_error("pt_upload_scene: mesh registered for geom %d, which is not a MESH of this scene", hm.geom_index); return PT_ERR_ARGUMENT; }
+        mesh_of[hm.geom_index] = &hm;
+        have_mesh = true;
+        if (c->cfg.direct_light != 0 && mats[geoms[hm.geom_index].materialid].emittance > 0.0f) { pth::set_error("pt_upload_scene: direct_light does not sample emitting meshes (geom %d)", hm.geom_index); return PT_ERR_ARGUMENT; }
     }
     const int stride = c->cfg.row_stride, offset = c->cfg.row_offset;
     const int rows = offset < H ? (H - offset + stride - 1) / stride : 0;
@@ -2464,6 +2652,25 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     c->binned = c->cull && c->cfg.ordering == 2 && c->cfg.geometry_path == 0 && G <= 32 && c->cfg.mode == 0;
     if (c->use_bvh) { c->defer = false; c->binned = false; c->queue = false; }
     c->geom_lds = (c->cfg.geometry_path == 0);
+    if (have_mesh) {
+        // meshes are traversed by the stable kernels only
+        c->defer = false; c->queue = false; c->binned = false; c->use_bvh = false;
+        for (int i = 0; i < G; ++i) {
+            if (!mesh_of[i]) continue;
+            uint32_t tri_offset = 0;
+            const std::vector<unsigned char> blob = build_mesh_blob(*mesh_of[i], &tri_offset);
+            void *d_blob = nullptr;
+            HIPCHK(hipMalloc(&d_blob, blob.size()));
+            c->d_mesh_blobs.push_back(d_blob);
+            HIPCHK(hipMemcpy(d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
+            const unsigned long long addr = (unsigned long long)(uintptr_t)d_blob;
+            const uint32_t lo32 = (uint32_t)addr, hi32 = (uint32_t)(addr >> 32);
+            mesh_world_bounds(geoms[i], *mesh_of[i], &g[i]);
+            memcpy(&g[i].bmin[3], &lo32, 4);
+            memcpy(&g[i].bmax[3], &hi32, 4);
+            g[i].inside_hits = (int)tri_offset;
+        }
+    }
     c->nee = c->cfg.direct_light != 0 && c->cfg.mode == 0;
     if (c->nee) {
         // one kernel family implements it: segmented compaction, culling, LDS tables, generation order
@@ -2520,7 +2727,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     }
     c->lds_bytes = c->use_bvh ? bvh_lds_bytes(G, M, c->nnodes) : tb + stage_bytes;
     // 33..256 primitives with the table in LDS: the mask-register / packed-list variant (PT_WIDE=0 turns it off)
-    c->wide = c->cull && c->geom_lds && !c->nee && !c->use_bvh && !c->defer && !c->binned && !c->queue && c->cfg.mode == 0 && G > 32 && G <= 256;
+    c->wide = c->cull && c->geom_lds && !c->nee && !c->use_bvh && !c->defer && !c->binned && !c->queue && !have_mesh && c->cfg.mode == 0 && G > 32 && G <= 256;
     if (const char *wv = getenv("PT_WIDE")) if (atoi(wv) == 0) c->wide = false;
     const void *fns[8] = {
         reinterpret_cast<const void *>(&k_bounce<true, false>), reinterpret_cast<const void *>(&k_bounce<false, false>),

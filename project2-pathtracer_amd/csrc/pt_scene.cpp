@@ -162,15 +162,23 @@ float num(const std::vector<std::string> &t, size_t i) { return i < t.size() ? (
 
 struct ObjectFrames {
     int type = 0, material = 0;
+    std::string mesh_file;                     // MESH: the `<name>.obj` of the type line
     std::vector<Vec3> trans, rot, scale;
     std::vector<std::vector<float>> xf, inv;   // 16 floats each
 };
 
 }  // namespace
 
+struct LoadedMesh {
+    int geom_index = 0;
+    std::vector<float> vertices;               // x y z
+    std::vector<int> indices;                  // 3 per triangle, 0-based
+};
+
 struct pt_scene {
     std::vector<pt_material> materials;
     std::vector<ObjectFrames> objects;
+    std::vector<LoadedMesh> meshes;
     float res[2] = {0, 0};
     float fov[2] = {0, 0};
     int iterations = 0;
@@ -224,6 +232,44 @@ void camera_basis(const pt_camera *cam, const pt_config *cfg, ptd::CamRec *out) 
 }
 
 }  // namespace pth
+
+// Wavefront OBJ subset for MESH objects: `v x y z [w]` and `f i j k ...` (polygons fanned around their first
+// vertex; `i/t/n` forms use the vertex index; negative indices count from the end).  Everything else is ignored.
+// The reference never opens the file (src/scene.cpp:55-64 only tags the object), so a missing file is not an
+// error: the object then stays a MESH without data and is skipped, as in the reference.  0 ok / 1 absent / -1 bad.
+static int read_obj(const std::string &path, LoadedMesh *m) {
+    std::ifstream in(path.c_str());
+    if (!in.good()) return 1;
+    std::string line;
+    while (std::getline(in, line)) {
+        if (!line.empty() && line[line.size() - 1] == '\r') line.erase(line.size() - 1);
+        std::istringstream ls(line);
+        std::string tag;
+        ls >> tag;
+        if (tag == "v") {
+            float x = 0, y = 0, z = 0;
+            ls >> x >> y >> z;
+            if (ls.fail()) { pth::set_error("%s: malformed vertex line '%s'", path.c_str(), line.c_str()); return -1; }
+            m->vertices.push_back(x); m->vertices.push_back(y); m->vertices.push_back(z);
+        } else if (tag == "f") {
+            std::vector<int> poly;
+            std::string w;
+            while (ls >> w) {
+                const int raw = atoi(w.c_str());                   // stops at the first '/'
+                const int nv = (int)(m->vertices.size() / 3);
+                const int idx = raw > 0 ? raw - 1 : nv + raw;
+                if (raw == 0 || idx < 0 || idx >= nv) { pth::set_error("%s: face index %s out of range (%d vertices so far)", path.c_str(), w.c_str(), nv); return -1; }
+                poly.push_back(idx);
+            }
+            if (poly.size() < 3) { pth::set_error("%s: face with %zu vertices", path.c_str(), poly.size()); return -1; }
+            for (size_t k = 1; k + 1 < poly.size(); ++k) {
+                m->indices.push_back(poly[0]); m->indices.push_back(poly[k]); m->indices.push_back(poly[k + 1]);
+            }
+        }
+    }
+    if (m->indices.empty()) { pth::set_error("%s: no faces", path.c_str()); return -1; }
+    return 0;
+}
 
 extern "C" {
 
@@ -332,7 +378,7 @@ int pt_scene_load(const char *path, pt_scene **out) {
                 std::string ext = dot == std::string::npos ? "" : line.substr(dot + 1);
                 const size_t dot2 = ext.find('.');
                 if (dot2 != std::string::npos) ext = ext.substr(0, dot2);
-                if (ext == "obj") o.type = 2;
+                if (ext == "obj") { o.type = 2; o.mesh_file = line; }
                 else {
                     pth::set_error("ERROR: %s is not a valid object type!", line.c_str());
                     delete s;
@@ -389,7 +435,32 @@ int pt_scene_load(const char *path, pt_scene **out) {
             delete s;
             return PT_ERR_PARSE;
         }
+    // MESH objects: `<name>.obj` relative to the scene file's directory
+    {
+        std::string dir(path);
+        const size_t slash = dir.find_last_of('/');
+        dir = slash == std::string::npos ? "" : dir.substr(0, slash + 1);
+        for (size_t i = 0; i < s->objects.size(); ++i) {
+            if (s->objects[i].type != 2) continue;
+            LoadedMesh m;
+            m.geom_index = (int)i;
+            const int rc = read_obj(dir + s->objects[i].mesh_file, &m);
+            if (rc < 0) { delete s; return PT_ERR_PARSE; }
+            if (rc == 0) s->meshes.push_back(m);
+        }
+    }
     *out = s;
+    return PT_OK;
+}
+
+int pt_scene_mesh_count(const pt_scene *s) { return s ? (int)s->meshes.size() : 0; }
+
+int pt_scene_mesh(const pt_scene *s, int k, pt_mesh *mesh) {
+    if (!s || !mesh || k < 0 || k >= (int)s->meshes.size()) { pth::set_error("pt_scene_mesh: bad argument"); return PT_ERR_ARGUMENT; }
+    const LoadedMesh &m = s->meshes[(size_t)k];
+    mesh->geom_index = m.geom_index;
+    mesh->vertices = m.vertices.data(); mesh->nvertices = (int)(m.vertices.size() / 3);
+    mesh->indices = m.indices.data(); mesh->ntriangles = (int)(m.indices.size() / 3);
     return PT_OK;
 }
 

@@ -28,6 +28,8 @@ def make_tracer(scene, depth=8, **kw):
     pkg = load_package()
     cfg = pkg.default_config(max_depth=depth, **kw)
     tr = pkg.PathTracer(cfg)
+    if getattr(scene, "meshes", None):
+        tr.set_meshes(scene.meshes)
     tr.upload(*to_product(scene))
     return tr
 

@@ -105,6 +105,12 @@ def lib():
     L.orc_trace_pool.argtypes = [C.POINTER(Geom), C.c_int, C.POINTER(Material), C.c_int, C.POINTER(Camera),
                                  C.POINTER(Config), C.c_int, C.c_int] + [f3] * 9 + [C.POINTER(C.c_uint32)]
     L.orc_max_threads.restype = C.c_int
+    pf, pi = C.POINTER(C.c_float), C.POINTER(C.c_int)
+    L.orc_set_meshes.restype = C.c_int
+    L.orc_set_meshes.argtypes = [pi, C.POINTER(pf), pi, C.POINTER(pi), pi, C.c_int]
+    L.orc_triangle_test.restype = C.c_float; L.orc_triangle_test.argtypes = [f3, f3, f3, f3, f3]
+    L.orc_mesh_test.restype = C.c_float
+    L.orc_mesh_test.argtypes = [C.POINTER(Geom), pf, pi, C.c_int, f3, f3, f3, f3, pi]
     _lib = L
     return L
 
@@ -128,9 +134,10 @@ def vec3(*v):
 class Scene:
     """Flattened scene for one frame: what cudaRaytraceCore builds at raytraceKernel.cu:179-206."""
 
-    def __init__(self, geoms, materials, camera, iterations=1, image_name=""):
+    def __init__(self, geoms, materials, camera, iterations=1, image_name="", meshes=None):
         self.geoms, self.materials, self.camera = geoms, materials, camera
         self.iterations, self.image_name = iterations, image_name
+        self.meshes = list(meshes or [])      # [(geom_index, vertices float32 [n,3], indices int32 [t,3])]
 
     @property
     def G(self):
@@ -166,7 +173,61 @@ class Scene:
         xscaled = np.float32(np.float32(yscaled * np.float32(W)) / np.float32(H))
         fovx = np.float32(np.float32(np.float32(math.atan(float(xscaled))) * np.float32(180)) / pi)
         cam.fov[0], cam.fov[1] = float(fovx), float(fovy)
-        return Scene(self.geoms, self.materials, cam, self.iterations, self.image_name)
+        return Scene(self.geoms, self.materials, cam, self.iterations, self.image_name, self.meshes)
+
+
+class registered_meshes:
+    """with registered_meshes(scene): ...  -- the oracle's MESH registry holds the scene's meshes inside the block"""
+
+    def __init__(self, scene):
+        self.scene = scene
+
+    def __enter__(self):
+        ms = self.scene.meshes
+        n = len(ms)
+        self.keep = [(np.ascontiguousarray(v, np.float32), np.ascontiguousarray(i, np.int32)) for _, v, i in ms]
+        pf, pi = C.POINTER(C.c_float), C.POINTER(C.c_int)
+        gi = (C.c_int * max(1, n))(*[int(m[0]) for m in ms])
+        vp = (pf * max(1, n))(*[v.ctypes.data_as(pf) for v, _ in self.keep])
+        nv = (C.c_int * max(1, n))(*[len(v) for v, _ in self.keep])
+        ip = (pi * max(1, n))(*[i.ctypes.data_as(pi) for _, i in self.keep])
+        nt = (C.c_int * max(1, n))(*[len(i) for _, i in self.keep])
+        self.args = (gi, vp, nv, ip, nt)
+        assert lib().orc_set_meshes(gi, vp, nv, ip, nt, n) == 0
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_meshes(None, None, None, None, None, 0)
+        return False
+
+
+def read_obj(path):
+    """Independent reader of the OBJ subset the product's loader accepts: (vertices float32 [n,3], triangles int32 [t,3])"""
+    v, f = [], []
+    for line in open(path):
+        t = line.split()
+        if not t:
+            continue
+        if t[0] == "v":
+            v.append([float(x) for x in t[1:4]])
+        elif t[0] == "f":
+            poly = []
+            for w in t[1:]:
+                raw = int(w.split("/")[0])
+                poly.append(raw - 1 if raw > 0 else len(v) + raw)
+            for k in range(1, len(poly) - 1):
+                f.append([poly[0], poly[k], poly[k + 1]])
+    return np.array(v, np.float32), np.array(f, np.int32)
+
+
+def scene_meshes(scene_txt):
+    """[(geom_index, vertices, indices)] for the `*.obj` objects of a scene file (paths relative to the file)"""
+    out, lines = [], open(scene_txt).read().splitlines()
+    for k, line in enumerate(lines):
+        if line.startswith("OBJECT ") and k + 1 < len(lines) and lines[k + 1].endswith(".obj"):
+            v, f = read_obj(os.path.join(os.path.dirname(scene_txt), lines[k + 1]))
+            out.append((int(line.split()[1]), v, f))
+    return out
 
 
 def load_golden_scene(name, frame=0):
@@ -195,7 +256,10 @@ def load_golden_scene(name, frame=0):
         cam.view[k] = f32_from_bits(c["views"][frame][k])
         cam.up[k] = f32_from_bits(c["ups"][frame][k])
     cam.fov[0], cam.fov[1] = (f32_from_bits(v) for v in c["fov"])
-    return Scene(geoms, mats, cam, c["iterations"], c["imageName"])
+    meshes = []
+    if any(g.type == 2 for g in geoms):       # the reference's parser drops the file name: take it from the scene text
+        meshes = scene_meshes(os.path.join(ROOT, "scenes", name + ".txt"))
+    return Scene(geoms, mats, cam, c["iterations"], c["imageName"], meshes)
 
 
 def scene_from_pods(geoms, materials, camera):
@@ -231,8 +295,9 @@ def render(scene, cfg, first=1, count=1, image=None, nthreads=0):
     if image is None:
         image = np.zeros((scene.H, scene.W, 3), np.float32)
     live = np.zeros(cfg.max_depth + 1, np.uint64)
-    rc = L.orc_render(scene.geom_array(), scene.G, scene.material_array(), scene.M, C.byref(scene.camera),
-                      C.byref(cfg), first, count, fptr(image), live.ctypes.data_as(C.POINTER(C.c_uint64)), nthreads)
+    with registered_meshes(scene):
+        rc = L.orc_render(scene.geom_array(), scene.G, scene.material_array(), scene.M, C.byref(scene.camera),
+                          C.byref(cfg), first, count, fptr(image), live.ctypes.data_as(C.POINTER(C.c_uint64)), nthreads)
     assert rc == 0
     return image, live
 
@@ -242,8 +307,9 @@ def raycast_flat(scene, image=None, nthreads=0):
     if image is None:
         image = np.zeros((scene.H, scene.W, 3), np.float32)
     hit = np.zeros((scene.H, scene.W), np.int32)
-    rc = L.orc_raycast_flat(scene.geom_array(), scene.G, scene.material_array(), scene.M, C.byref(scene.camera),
-                            fptr(image), hit.ctypes.data_as(C.POINTER(C.c_int)), nthreads)
+    with registered_meshes(scene):
+        rc = L.orc_raycast_flat(scene.geom_array(), scene.G, scene.material_array(), scene.M, C.byref(scene.camera),
+                                fptr(image), hit.ctypes.data_as(C.POINTER(C.c_int)), nthreads)
     assert rc == 0
     return image, hit
 
@@ -253,7 +319,8 @@ def trace_pool(scene, cfg, iteration, bounces):
     n = scene.W * scene.H
     arrs = [np.zeros(n, np.float32) for _ in range(9)]
     pix = np.zeros(n, np.uint32)
-    cnt = L.orc_trace_pool(scene.geom_array(), scene.G, scene.material_array(), scene.M, C.byref(scene.camera),
-                           C.byref(cfg), iteration, bounces, *[fptr(a) for a in arrs],
-                           pix.ctypes.data_as(C.POINTER(C.c_uint32)))
+    with registered_meshes(scene):
+        cnt = L.orc_trace_pool(scene.geom_array(), scene.G, scene.material_array(), scene.M, C.byref(scene.camera),
+                               C.byref(cfg), iteration, bounces, *[fptr(a) for a in arrs],
+                               pix.ctypes.data_as(C.POINTER(C.c_uint32)))
     return cnt, [a[:cnt] for a in arrs], pix[:cnt]

@@ -1,0 +1,111 @@
+"""-m gpu: GEOMTYPE MESH on the HIP path (OBJ triangles behind a per-mesh threaded BVH) against
+the oracle's brute-force loop over the triangles.  Bit-exact like every other parity test: same nearest triangle (ties to
+the earlier one), same hit point / normal / depth, hence same images, live counts and ray pools."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import orc
+from gpu_common import make_tracer, oracle_config
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mesh_scene():
+    return orc.load_golden_scene("cornell_mesh").with_resolution(200, 150)
+
+
+def test_mesh_primary_hits_match_brute_force(pt, mesh_scene):
+    tr = make_tracer(mesh_scene)
+    d, hit, t, P, N = tr.primary_hits()
+    _, ohit = orc.raycast_flat(mesh_scene)
+    assert np.array_equal(ohit.reshape(-1), hit)
+    assert {6, 7, 8} <= set(np.unique(hit))
+    L = orc.lib()
+    cb = orc.CameraBasis()
+    L.orc_camera_setup(C.byref(mesh_scene.camera), C.byref(cb))
+    ga = mesh_scene.geom_array()
+    o, dd, PP, NN, tt = (C.c_float * 3)(), (C.c_float * 3)(), (C.c_float * 3)(), (C.c_float * 3)(), C.c_float()
+    on_mesh = np.flatnonzero((hit >= 6) & (hit <= 8))
+    rng = np.random.default_rng(5)
+    with orc.registered_meshes(mesh_scene):
+        for idx in np.concatenate([rng.choice(on_mesh, 1500), rng.integers(0, 200 * 150, 500)]):
+            x, y = int(idx % 200), int(idx // 200)
+            L.orc_camera_ray(C.byref(cb), None, x, y, 0, 0, 0, 0, o, dd)
+            h = L.orc_nearest_hit(ga, mesh_scene.G, None, o, dd, C.byref(tt), PP, NN)
+            assert h == hit[idx] and tt.value == t[idx]
+            if h >= 0:
+                assert np.array_equal(np.array(list(PP), np.float32), P[idx]) and np.array_equal(np.array(list(NN), np.float32), N[idx])
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(culling=1), dict(geometry_path=1), dict(compaction=1), dict(batch=2, chunk_rays=100),
+                                dict(streams=2), dict(ordering=1), dict(bvh=1), dict(direct_light=1), dict(culling=1, geometry_path=1)])
+def test_mesh_scene_matches_oracle(pt, mesh_scene, kw):
+    """mirror torus, glass tetrahedron (rays start inside it), diffuse icosphere, next to a sphere and a rotated cube"""
+    depth, iters = 6, 3
+    tr = make_tracer(mesh_scene, depth=depth, **kw)
+    tr.set_image(None)
+    tr.render(1, iters)
+    okw = {k: v for k, v in kw.items() if k == "direct_light"}
+    want, live = orc.render(mesh_scene, oracle_config(depth, **okw), 1, iters)
+    st = tr.stats()
+    assert [st.live[k] for k in range(depth + 1)] == [int(v) for v in live]
+    assert np.array_equal(tr.image(), want)
+    if kw.get("streams", 1) == 1:
+        n, arrs, pix = tr.trace_pool(2, 3)
+        on, oarrs, opix = orc.trace_pool(mesh_scene, oracle_config(depth, **okw), 2, 3)
+        assert n == on and np.array_equal(pix, opix) and all(np.array_equal(a, b) for a, b in zip(arrs, oarrs))
+    tr.close()
+
+
+def test_mesh_without_data_is_skipped_and_meshes_can_be_cleared(pt, mesh_scene):
+    bare = orc.Scene(mesh_scene.geoms, mesh_scene.materials, mesh_scene.camera)
+    tr = make_tracer(bare, depth=5)
+    tr.set_image(None); tr.render(1, 2)
+    want, _ = orc.render(bare, oracle_config(5), 1, 2)
+    assert np.array_equal(tr.image(), want)
+    tr.close()
+    from gpu_common import to_product
+    tr = make_tracer(mesh_scene, depth=5)
+    tr.set_meshes([])                                      # cleared: the next upload sees plain MESH tags again
+    tr.upload(*to_product(mesh_scene))
+    tr.set_image(None); tr.render(1, 2)
+    assert np.array_equal(tr.image(), want)
+    with pytest.raises(pt.PtError, match="not a MESH"):
+        tr.set_meshes([(0, mesh_scene.meshes[0][1], mesh_scene.meshes[0][2])])
+        tr.upload(*to_product(mesh_scene))
+    tr.close()
+
+
+def test_larger_mesh_and_odd_scales(pt):
+    """5 120-triangle icosphere (deeper BVH), scaled 0.05x and 40x with the whole scene: the BVH's margins are relative"""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from make_scenes import icosphere
+    v, f = icosphere(4)
+    v, f = np.array(v, np.float32), np.array(f, np.int32)
+    base = orc.load_golden_scene("cornell_mesh").with_resolution(160, 120)
+    for factor in (1.0, 0.05, 40.0):
+        geoms = []
+        for g0 in base.geoms:
+            g = orc.Geom()
+            C.memmove(C.byref(g), C.byref(g0), C.sizeof(orc.Geom))
+            for r in range(3):
+                for c in range(4):
+                    g.transform[4 * r + c] = g0.transform[4 * r + c] * factor
+                    g.inverseTransform[4 * r + c] = g0.inverseTransform[4 * r + c] / factor if c < 3 else g0.inverseTransform[4 * r + c]
+            geoms.append(g)
+        cam = orc.Camera()
+        C.memmove(C.byref(cam), C.byref(base.camera), C.sizeof(orc.Camera))
+        for k in range(3):
+            cam.position[k] = base.camera.position[k] * factor
+        sc = orc.Scene(geoms, base.materials, cam, meshes=[(6, v, f)] + base.meshes[1:])
+        tr = make_tracer(sc, depth=5)
+        tr.set_image(None); tr.render(1, 2)
+        want, live = orc.render(sc, oracle_config(5), 1, 2)
+        st = tr.stats()
+        assert [st.live[k] for k in range(6)] == [int(x) for x in live], factor
+        assert np.array_equal(tr.image(), want), factor
+        tr.close()

@@ -11,7 +11,12 @@ These are the build's own files (typed from parameter tables below, no comments,
   cornell_mirror.txt     config 3: 1920x1080, materials 3,4,6 are perfect mirrors (REFL 1)
   random256.txt          config 4: Cornell shell + 250 random spheres/cubes, seed 565, 1920x1080
   cornell_glass_4k.txt   config 5: 3840x2160, sphere 5 uses the glass material (REFR 1, IOR 2.2)
+  cornell_mesh.txt       GEOMTYPE MESH (the reference only declares it): Cornell shell + light + three `*.obj` objects
+                         -- a 320-triangle icosphere (diffuse), a quad-faced torus (mirror) and a glass tetrahedron,
+                         rotated and non-uniformly scaled -- next to one sphere and one cube
+  meshes/*.obj           the meshes, generated below (v / f lines only)
 """
+import math
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -114,9 +119,82 @@ def random256(seed=565, extra=250):
     return mats, objs
 
 
+def icosphere(level):
+    """unit-diameter icosphere, `level` subdivisions (20 * 4^level triangles)"""
+    t = (1.0 + math.sqrt(5.0)) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
+         (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+         (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    v = [tuple(c / math.sqrt(1 + t * t) for c in p) for p in v]
+    for _ in range(level):
+        mid, nf = {}, []
+
+        def m(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in mid:
+                p = [(v[a][k] + v[b][k]) / 2 for k in range(3)]
+                n = math.sqrt(sum(c * c for c in p))
+                v.append(tuple(c / n for c in p))
+                mid[key] = len(v) - 1
+            return mid[key]
+        for a, b, c in f:
+            ab, bc, ca = m(a, b), m(b, c), m(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    return [tuple(0.5 * c for c in p) for p in v], f
+
+
+def torus(nu, nv, R=0.35, r=0.15):
+    """quad faces (the loader fans them); axis = y"""
+    v, f = [], []
+    for i in range(nu):
+        a = 2 * math.pi * i / nu
+        for j in range(nv):
+            b = 2 * math.pi * j / nv
+            v.append(((R + r * math.cos(b)) * math.cos(a), r * math.sin(b), (R + r * math.cos(b)) * math.sin(a)))
+    for i in range(nu):
+        for j in range(nv):
+            f.append((i * nv + j, ((i + 1) % nu) * nv + j, ((i + 1) % nu) * nv + (j + 1) % nv, i * nv + (j + 1) % nv))
+    return v, f
+
+
+def write_obj(path, v, f, relative=False):
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w", newline="\n") as fh:
+        fh.write("# generated by tools/make_scenes.py\n")
+        for p in v:
+            fh.write("v %.6f %.6f %.6f\n" % p)
+        for face in f:
+            if relative:                       # negative indices count back from the last vertex
+                fh.write("f " + " ".join(str(i - len(v)) for i in face) + "\n")
+            else:
+                fh.write("f " + " ".join("%d/%d/%d" % (i + 1, i + 1, i + 1) if len(face) == 4 else str(i + 1) for i in face) + "\n")
+
+
+def mesh_scene(out):
+    v, f = icosphere(2)
+    write_obj(os.path.join(out, "meshes", "icosphere.obj"), v, f)
+    v, f = torus(20, 10)
+    write_obj(os.path.join(out, "meshes", "torus.obj"), v, f)
+    tet = [(-.5, -.5, -.5), (.5, -.5, .5), (-.5, .5, .5), (.5, .5, -.5)]
+    write_obj(os.path.join(out, "meshes", "tetra.obj"), tet, [(0, 1, 2), (0, 3, 1), (0, 2, 3), (1, 3, 2)], relative=True)
+    mats = list(CORNELL_MATERIALS)
+    m = list(mats[4]); m[3] = 1; mats[4] = tuple(m)                 # 4: white mirror
+    objs = [o for o in CORNELL_OBJECTS[:5]] + [CORNELL_OBJECTS[8]] + [
+        ("meshes/icosphere.obj", 2, (-2.2, 2.0, 0.5), (20, 35, 0), (3.4, 3.0, 3.4)),
+        ("meshes/torus.obj", 4, (1.8, 3.2, -1.0), (60, 20, 10), (5.5, 5.5, 5.5)),
+        ("meshes/tetra.obj", 5, (0.4, 1.2, 2.6), (0, 30, 0), (2.0, 2.4, 2.0)),
+        ("sphere", 1, (2.6, 6.8, 1.5), (0, 0, 0), (2, 2, 2)),
+        ("cube", 0, (-2.8, 6.5, -2.0), (25, 40, 10), (1.6, 1.6, 1.6)),
+    ]
+    write_scene(os.path.join(out, "cornell_mesh.txt"), mats, objs, (800, 600), 500, "renders/cornell_mesh.bmp", frames=1)
+
+
 def main():
     out = os.path.join(ROOT, "scenes")
     os.makedirs(out, exist_ok=True)
+    mesh_scene(out)
     write_scene(os.path.join(out, "cornell.txt"), CORNELL_MATERIALS, CORNELL_OBJECTS, (800, 800), 5000,
                 "renders/sampleScene.bmp")
     write_scene(os.path.join(out, "cornell_c1.txt"), CORNELL_MATERIALS, CORNELL_OBJECTS, (400, 400), 1,
