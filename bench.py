@@ -197,6 +197,7 @@ def main():
                     help="contexts per GPU, each on its own HIP stream and owning every (streams*gpus)-th row: the tails of one "
                          "context's launches are filled by the other's (bit-identical, like the multi-GPU sharding); 1 = off")
     ap.add_argument("--direct-light", type=int, default=0, help="1 = next-event estimation (one shadow ray per diffuse hit); not the headline configuration")
+    ap.add_argument("--warm-passes", type=int, default=0, help="untimed K-step passes before the timed ones (0 = until the pass time has settled; profiling runs fix it)")
     ap.add_argument("--repeats", type=int, default=7, help="the exact K-step timed pass is repeated this many times; value = the median pass")
     args = ap.parse_args()
 
@@ -306,10 +307,12 @@ def main():
     #    back-to-back 4 ms passes measured 4.39 -> 3.98 ms).  At least one, at most 40 passes or 0.4 s.
     #    (Every quantity in the loop condition is the all-reduced pass time, so all ranks take the same decisions.)
     warm_passes, settled, prev, warm_total = 0, 0, None, 0.0
-    while warm_passes < 40 and warm_total < 0.4:
+    while warm_passes < (args.warm_passes or 40) and (args.warm_passes or warm_total < 0.4):
         cur = timed_pass(args.warmup + 1, False)
         warm_passes += 1
         warm_total += cur
+        if args.warm_passes:
+            continue
         settled = settled + 1 if prev is not None and abs(cur - prev) <= 0.01 * cur else 0
         prev = cur
         if settled >= 3:

@@ -23,6 +23,7 @@
 // Options the reference has no channel for come from the environment:
 //   PT_MODE=pathtrace|reference  PT_MAX_DEPTH  PT_CAMERA_MODE  PT_AA  PT_APERTURE  PT_FOCAL_DIST
 //   PT_DIRECT_LIGHT  PT_STREAMS  PT_DEVICE  PT_PBO_IS_DEVICE  PT_SYNC_EVERY_CALL  PT_LAZY_BATCH  PT_NGPU  PT_DEVICES
+//   PT_DUMP_IMAGE=<file> (test hook: camera::image as raw floats after the final iteration)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -222,5 +223,11 @@ void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iteratio
             if (pt_display(g_ctx, scale, PBOpos, g_pbo_is_device) != PT_OK) die("pt_display");
         }
     }
-    if (download) gather_image(reinterpret_cast<float *>(renderCam->image), W, H);
+    if (download) {
+        gather_image(reinterpret_cast<float *>(renderCam->image), W, H);
+        // test hook: the raw accumulator the caller now holds (the viewer only ever saves its gamma-corrected bytes)
+        if (final_call)
+            if (const char *path = getenv("PT_DUMP_IMAGE"))
+                if (FILE *f = fopen(path, "wb")) { fwrite(renderCam->image, sizeof(float) * 3, (size_t)W * H, f); fclose(f); }
+    }
 }

@@ -1,7 +1,11 @@
-"""The drop-in boundary: the reference's OWN host code (scene.cpp, utilities.cpp, image.cpp compiled
-from /root/reference where they lie) driving the HIP library through the adaptor's
-`cudaRaytraceCore` symbol.  oracle/_ref/dropin_driver is built in the container by oracle/Makefile
-and travels to the GPU box as a binary (the reference sources do not)."""
+"""The drop-in boundary: the reference's OWN host code -- main.cpp, glslUtility.cpp, scene.cpp, utilities.cpp,
+image.cpp, compiled UNCHANGED from /root/reference where they lie against the product's headless shim include
+directory (project2-pathtracer_amd/shim) -- driving the HIP library through the adaptor's `cudaRaytraceCore`
+symbol.  oracle/_ref/main_dropin is built in the container by oracle/Makefile and travels to the GPU box as a binary
+(the reference sources do not).  The viewer's own command line is used (`scene=... frame=N`); it saves
+renders/<name>.<frame>.bmp relative to the working directory and needs shaders/passthrough{VS,FS}.glsl there
+(src/main.cpp:75, src/glslUtility.cpp:19-37).  Test hooks of the adaptor / shim: PT_DUMP_IMAGE (raw accumulator),
+PT_SHIM_PBO_DUMP (last display buffer), PT_SHIM_NO_PBO (no mapped display buffer)."""
 import hashlib
 import json
 import os
@@ -14,28 +18,42 @@ import pytest
 import orc
 from conftest import ROOT, has_reference, load_package
 
-DRIVER = os.path.join(ROOT, "oracle", "_ref", "dropin_driver")
+DRIVER = os.path.join(ROOT, "oracle", "_ref", "main_dropin")
 K = json.load(open(os.path.join(orc.GOLD, "survey_kats.json")))
 
 
-@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "adaptor.o")), reason="oracle/_ref not built")
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "shim_adaptor.o")), reason="oracle/_ref not built")
 def test_adaptor_defines_the_reference_symbol():
     """Same mangled name as the declaration in /root/reference/src/raytraceKernel.h:18 produces in
     main.cpp (types `uchar4`, `camera`, `material`, `geom` from the reference/CUDA headers)."""
-    out = subprocess.run(["nm", os.path.join(ROOT, "oracle", "_ref", "adaptor.o")], capture_output=True, text=True).stdout
+    out = subprocess.run(["nm", os.path.join(ROOT, "oracle", "_ref", "shim_adaptor.o")], capture_output=True, text=True).stdout
     assert " T _Z16cudaRaytraceCoreP6uchar4P6cameraiiP8materialiP4geomi" in out
     assert "ptmi355_adaptor_reset" in out
+    # ... and the unchanged main.cpp asks for exactly that symbol
+    main_o = subprocess.run(["nm", os.path.join(ROOT, "oracle", "_ref", "shim_main.o")], capture_output=True, text=True).stdout
+    assert " U _Z16cudaRaytraceCoreP6uchar4P6cameraiiP8materialiP4geomi" in main_o and " U cudaDeviceReset" in main_o
 
 
-@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref/dropin_driver not built")
+@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref/main_dropin not built")
 def test_error_convention_without_gpu(tmp_path):
     pkg = load_package()
     if pkg.lib().pt_device_count() > 0:
         pytest.skip("a GPU is present")
-    r = subprocess.run([DRIVER, "scene=" + os.path.join(ROOT, "scenes", "cornell_c1.txt"), "out=" + str(tmp_path)],
-                       capture_output=True, text=True, cwd=ROOT)
+    r = run_viewer(str(tmp_path), os.path.join(ROOT, "scenes", "cornell_c1.txt"))
     assert r.returncode == 1                                        # exit(EXIT_FAILURE)
     assert r.stderr.startswith("Cuda error: ") and r.stderr.rstrip().endswith(".")   # raytraceKernel.cu:23
+
+
+def run_viewer(workdir, scene, frame=0, **env):
+    """the reference's unchanged main(): `scene=<file> frame=<n>` in a directory holding shaders/ and renders/"""
+    os.makedirs(os.path.join(workdir, "shaders"), exist_ok=True)
+    os.makedirs(os.path.join(workdir, "renders"), exist_ok=True)
+    for name in ("passthroughVS.glsl", "passthroughFS.glsl"):
+        with open(os.path.join(workdir, "shaders", name), "w") as f:
+            f.write("void main() {}\n")
+    e = dict(os.environ, PT_DUMP_IMAGE=os.path.join(workdir, "image.f32"), PT_SHIM_PBO_DUMP=os.path.join(workdir, "pbo.u8"))
+    e.update({k: str(v) for k, v in env.items()})
+    return subprocess.run([DRIVER, "scene=" + scene, "frame=%d" % frame], capture_output=True, text=True, cwd=workdir, env=e, timeout=600)
 
 
 def _retarget(text, w, h, iters):
@@ -55,16 +73,15 @@ def _small_scene(tmp_path, w, h, iters):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref/dropin_driver not built")
+@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref/main_dropin not built")
 def test_config1_through_reference_host_code(tmp_path):
     """BASELINE config 1 through the reference's scene parser, the adaptor, the HIP library in
     reference-kernel mode and the reference's image writer: the saved BMP's raster is the one the
     unchanged reference produced (sha256 from the survey)."""
-    env = dict(os.environ, PT_MODE="reference")
-    r = subprocess.run([DRIVER, "scene=" + os.path.join(ROOT, "scenes", "cornell_c1.txt"), "frame=0", "out=" + str(tmp_path)],
-                       capture_output=True, text=True, cwd=ROOT, env=env)
+    r = run_viewer(str(tmp_path), os.path.join(ROOT, "scenes", "cornell_c1.txt"), PT_MODE="reference")
     assert r.returncode == 0, r.stderr
-    bmp = (tmp_path / "sampleScene.0.bmp").read_bytes()
+    assert "Saved frame 0 to renders/sampleScene.0.bmp" in r.stdout
+    bmp = (tmp_path / "renders" / "sampleScene.0.bmp").read_bytes()
     assert len(bmp) == K["c1_bmp"]["file_bytes"]
     rows = [bmp[54 + y * 1200: 54 + (y + 1) * 1200] for y in range(399, -1, -1)]
     raster = np.frombuffer(b"".join(rows), np.uint8).reshape(400, 400, 3)[:, :, ::-1]
@@ -72,14 +89,13 @@ def test_config1_through_reference_host_code(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref/dropin_driver not built")
+@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref/main_dropin not built")
 def test_path_trace_through_reference_host_code(tmp_path):
     pkg = load_package()
     scene_path = _small_scene(tmp_path, 64, 48, 3)
-    env = dict(os.environ, PT_MODE="pathtrace", PT_MAX_DEPTH="5")
-    r = subprocess.run([DRIVER, "scene=" + scene_path, "out=" + str(tmp_path)], capture_output=True, text=True, cwd=ROOT, env=env)
+    r = run_viewer(str(tmp_path), scene_path, PT_MODE="pathtrace", PT_MAX_DEPTH=5)
     assert r.returncode == 0, r.stderr
-    got = np.fromfile(str(tmp_path / "cornell_mirror.0.bmp.f32"), np.float32).reshape(48, 64, 3)
+    got = np.fromfile(str(tmp_path / "image.f32"), np.float32).reshape(48, 64, 3)
     sf = pkg.SceneFile(scene_path)
     geoms, mats, cam = sf.flatten(0)
     import ctypes as C
@@ -98,11 +114,11 @@ def test_path_trace_through_reference_host_code(tmp_path):
     # the saved file = gamma/clamp/u8 of that sum with divisor = iterations, through the reference's image class
     ref_u8 = np.zeros(48 * 64 * 3, np.uint8)
     orc.lib().orc_image_to_u8(orc.fptr(want), 48 * 64, 3.0, float(np.float32(1 / 2.2)), ref_u8.ctypes.data_as(C.POINTER(C.c_uint8)))
-    bmp = (tmp_path / "cornell_mirror.0.bmp").read_bytes()
+    bmp = (tmp_path / "renders" / "cornell_mirror.0.bmp").read_bytes()
     rows = [bmp[54 + y * 192: 54 + (y + 1) * 192] for y in range(47, -1, -1)]
     assert np.array_equal(np.frombuffer(b"".join(rows), np.uint8).reshape(48, 64, 3)[:, :, ::-1].reshape(-1), ref_u8)
     # the PBO bytes of the last call: sendImageToPBO of sum/iterations
-    pbo = np.fromfile(str(tmp_path / "cornell_mirror.0.bmp.pbo"), np.uint8).reshape(-1, 4)
+    pbo = np.fromfile(str(tmp_path / "pbo.u8"), np.uint8).reshape(-1, 4)
     o = (C.c_uint8 * 4)()
     scale = np.float32(1.0) / np.float32(3)
     for idx in (0, 1000, 3071):
@@ -112,7 +128,7 @@ def test_path_trace_through_reference_host_code(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref/dropin_driver not built")
+@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref/main_dropin not built")
 def test_lazy_batching_behind_the_per_iteration_api(tmp_path):
     """PT_LAZY_BATCH: the adaptor queues per-iteration calls and renders them as one launch group;
     what the caller can observe (camera::image after the last iteration) is bit-identical."""
@@ -121,16 +137,15 @@ def test_lazy_batching_behind_the_per_iteration_api(tmp_path):
     for lazy, sub in (("1", "a"), ("4", "b"), ("16", "c")):
         out = tmp_path / sub
         out.mkdir()
-        env = dict(os.environ, PT_MODE="pathtrace", PT_MAX_DEPTH="5", PT_LAZY_BATCH=lazy)
-        r = subprocess.run([DRIVER, "scene=" + scene_path, "out=" + str(out), "pbo=0"], capture_output=True, text=True, cwd=ROOT, env=env)
+        r = run_viewer(str(out), scene_path, PT_MODE="pathtrace", PT_MAX_DEPTH=5, PT_LAZY_BATCH=lazy, PT_SHIM_NO_PBO=1)
         assert r.returncode == 0, r.stderr
-        outs.append(np.fromfile(str(out / "cornell_mirror.0.bmp.f32"), np.float32))
+        outs.append(np.fromfile(str(out / "image.f32"), np.float32))
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     assert outs[0].max() > 0
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref/dropin_driver not built")
+@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref/main_dropin not built")
 def test_frame_argument_selects_the_frame(tmp_path):
     """`frame=1` (src/main.cpp:39-42): the second frame of the scene file is flattened and rendered,
     the output is named X.1.bmp (src/main.cpp:148-154)."""
@@ -147,10 +162,10 @@ def test_frame_argument_selects_the_frame(tmp_path):
     p.write_text(text)
     outs = []
     for frame in (0, 1):
-        env = dict(os.environ, PT_MODE="pathtrace", PT_MAX_DEPTH="4")
-        r = subprocess.run([DRIVER, "scene=" + str(p), "frame=%d" % frame, "out=" + str(tmp_path)], capture_output=True, text=True, cwd=ROOT, env=env)
+        r = run_viewer(str(tmp_path), str(p), frame=frame, PT_MODE="pathtrace", PT_MAX_DEPTH=4)
         assert r.returncode == 0, r.stderr
-        outs.append(np.fromfile(str(tmp_path / ("cornell_mirror.%d.bmp.f32" % frame)), np.float32))
+        assert os.path.exists(str(tmp_path / "renders" / ("cornell_mirror.%d.bmp" % frame)))
+        outs.append(np.fromfile(str(tmp_path / "image.f32"), np.float32))
     assert not np.array_equal(outs[0], outs[1])
     pkg = load_package()
     sf = pkg.SceneFile(str(p))
@@ -172,7 +187,7 @@ def test_frame_argument_selects_the_frame(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref/dropin_driver not built")
+@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref/main_dropin not built")
 @pytest.mark.parametrize("ngpu,pbo", [(2, "0"), (3, "1")])
 def test_adaptor_shards_rows_over_several_contexts(tmp_path, ngpu, pbo):
     """PT_NGPU: the adaptor drives one context per GPU from the reference's single caller thread (rows
@@ -182,11 +197,11 @@ def test_adaptor_shards_rows_over_several_contexts(tmp_path, ngpu, pbo):
     for n in (1, ngpu):
         out = tmp_path / ("n%d" % n)
         out.mkdir()
-        env = dict(os.environ, PT_MODE="pathtrace", PT_MAX_DEPTH="5", PT_NGPU=str(n), PT_DEVICES=",".join(["0"] * n), PT_LAZY_BATCH="2")
-        r = subprocess.run([DRIVER, "scene=" + scene_path, "out=" + str(out), "pbo=" + pbo], capture_output=True, text=True, cwd=ROOT, env=env)
+        r = run_viewer(str(out), scene_path, PT_MODE="pathtrace", PT_MAX_DEPTH=5, PT_NGPU=n, PT_DEVICES=",".join(["0"] * n), PT_LAZY_BATCH=2,
+                       PT_SHIM_NO_PBO=0 if pbo == "1" else 1)
         assert r.returncode == 0, r.stderr
-        outs[n] = (np.fromfile(str(out / "cornell_mirror.0.bmp.f32"), np.float32), (out / "cornell_mirror.0.bmp").read_bytes(),
-                   np.fromfile(str(out / "cornell_mirror.0.bmp.pbo"), np.uint8))
+        outs[n] = (np.fromfile(str(out / "image.f32"), np.float32), (out / "renders" / "cornell_mirror.0.bmp").read_bytes(),
+                   np.fromfile(str(out / "pbo.u8"), np.uint8))
     assert np.array_equal(outs[1][0], outs[ngpu][0]) and outs[1][1] == outs[ngpu][1]
     if pbo == "1":
         assert np.array_equal(outs[1][2], outs[ngpu][2])

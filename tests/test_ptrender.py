@@ -2,7 +2,7 @@
 the command line, frame loop, file naming and messages of /root/reference/src/main.cpp on top of
 the C ABI alone -- no reference sources involved at build or run time.  On the GPU its files are
 compared byte for byte with the ones the reference's own scene/image code writes through the
-adaptor (oracle/_ref/dropin_driver) and with the survey's sha256 of the unchanged reference's BMP."""
+adaptor (oracle/_ref/main_dropin = the unchanged main.cpp) and with the survey's sha256 of the unchanged reference's BMP."""
 import hashlib
 import json
 import os
@@ -16,7 +16,7 @@ import orc
 from conftest import ROOT, load_package
 
 PTRENDER = os.path.join(ROOT, "project2-pathtracer_amd", "ptrender")
-DROPIN = os.path.join(ROOT, "oracle", "_ref", "dropin_driver")
+DROPIN = os.path.join(ROOT, "oracle", "_ref", "main_dropin")
 K = json.load(open(os.path.join(orc.GOLD, "survey_kats.json")))
 
 pytestmark = pytest.mark.skipif(not os.path.exists(PTRENDER), reason="ptrender not built (make -C project2-pathtracer_amd)")
@@ -92,10 +92,10 @@ def test_config1_bmp_is_the_reference_raster(tmp_path):
     if os.path.exists(DROPIN):
         d = tmp_path / "ref"
         d.mkdir()
-        r2 = subprocess.run([DROPIN, "scene=" + os.path.join(ROOT, "scenes", "cornell_c1.txt"), "frame=0", "out=" + str(d)],
-                            capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, PT_MODE="reference"))
+        from test_dropin import run_viewer
+        r2 = run_viewer(str(d), os.path.join(ROOT, "scenes", "cornell_c1.txt"), frame=0, PT_MODE="reference")
         assert r2.returncode == 0, r2.stderr
-        assert (d / "sampleScene.0.bmp").read_bytes() == bmp          # whole file, header included
+        assert (d / "renders" / "sampleScene.0.bmp").read_bytes() == bmp          # whole file, header included
 
 
 @pytest.mark.gpu
@@ -120,10 +120,10 @@ def test_frame_loop_names_and_oracle_parity(tmp_path):
         for f in (0, 1):
             d = tmp_path / ("ref%d" % f)
             d.mkdir()
-            r2 = subprocess.run([DROPIN, "scene=" + scene_path, "frame=%d" % f, "out=" + str(d)], capture_output=True, text=True,
-                                cwd=ROOT, env=dict(os.environ, PT_MODE="pathtrace", PT_MAX_DEPTH="5"))
+            from test_dropin import run_viewer
+            r2 = run_viewer(str(d), scene_path, frame=f, PT_MODE="pathtrace", PT_MAX_DEPTH=5)
             assert r2.returncode == 0, r2.stderr
-            assert (d / ("cornell_mirror.%d.bmp" % f)).read_bytes() == (tmp_path / ("cornell_mirror.%d.bmp" % f)).read_bytes()
+            assert (d / "renders" / ("cornell_mirror.%d.bmp" % f)).read_bytes() == (tmp_path / ("cornell_mirror.%d.bmp" % f)).read_bytes()
 
 
 @pytest.mark.gpu

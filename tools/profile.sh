@@ -10,7 +10,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 # 32 warm-up steps + 2 passes (one untimed, one timed: --repeats 1) of 64 steps = 160 rendered steps in FULL launch
 # groups (2 contexts x 32 iterations at 1080p), so the per-kernel averages are comparable with the default bench run
-BENCH="python3 $ROOT/bench.py --steps 64 --warmup 32 --repeats 1 --no-cpu-baseline --no-kernel-events $*"
+BENCH="python3 $ROOT/bench.py --steps 64 --warmup 32 --warm-passes 1 --repeats 1 --no-cpu-baseline --no-kernel-events $*"
 cd /tmp
 echo "== kernel trace"; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- $BENCH > "$OUT/kt.log" 2>&1 || { echo "kernel trace failed"; tail -5 "$OUT/kt.log"; exit 1; }
 [ -n "${KT_ONLY:-}" ] && { echo "kernel trace only"; exit 0; }
