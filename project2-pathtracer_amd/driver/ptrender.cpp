@@ -141,6 +141,16 @@ int main(int argc, char **argv) {
         ctxs.push_back(c);
     }
 
+    // MESH objects whose .obj the loader found: registered once, used by every upload
+    std::vector<pt_mesh> meshes((size_t)pt_scene_mesh_count(scene));
+    for (size_t k = 0; k < meshes.size(); ++k)
+        if (pt_scene_mesh(scene, (int)k, &meshes[k]) != PT_OK) die("pt_scene_mesh");
+    if (!meshes.empty()) {
+        for (pt_context *c : ctxs)
+            if (pt_set_meshes(c, meshes.data(), (int)meshes.size()) != PT_OK) die("pt_set_meshes");
+        printf("Loaded %zu mesh(es)\n", meshes.size());
+    }
+
     std::vector<pt_geom> geoms(G > 0 ? G : 1);
     std::vector<pt_material> materials(M > 0 ? M : 1);
     const int last = o.single_frame ? o.frame : frames - 1;

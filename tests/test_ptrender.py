@@ -142,3 +142,25 @@ def test_out_of_range_frame_and_two_contexts(tmp_path):
         assert len(f32) == 1 and ".0." in f32[0]
         outs.append(np.fromfile(str(d / f32[0]), np.float32))
     assert outs[0].max() > 0 and np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.gpu
+def test_mesh_scene_through_ptrender(tmp_path):
+    """scenes/cornell_mesh.txt: the loader finds the three .obj files beside the scene, ptrender registers them
+    (pt_scene_mesh -> pt_set_meshes) and the float sum equals the oracle's brute-force triangles"""
+    scene_path = os.path.join(ROOT, "scenes", "cornell_mesh.txt")
+    text = open(scene_path).read()
+    text, n = re.subn(r"^RES\s+\d+\s+\d+$", "RES 96 72", text, flags=re.M)
+    text, m = re.subn(r"^ITERATIONS\s+\d+$", "ITERATIONS 2", text, flags=re.M)
+    assert n == 1 and m == 1
+    import shutil
+    shutil.copytree(os.path.join(ROOT, "scenes", "meshes"), str(tmp_path / "meshes"))
+    p = tmp_path / "mesh_small.txt"
+    p.write_text(text)
+    r = _run(["scene=" + str(p), "frame=0", "out=" + str(tmp_path), "depth=5", "raw=1"])
+    assert r.returncode == 0, r.stderr
+    assert "Loaded 3 mesh(es)" in r.stdout
+    got = np.fromfile(str(tmp_path / "cornell_mesh.0.bmp.f32"), np.float32).reshape(72, 96, 3)
+    sc = orc.load_golden_scene("cornell_mesh").with_resolution(96, 72)
+    want, _ = orc.render(sc, orc.default_config(5), 1, 2)
+    assert np.array_equal(got, want)
