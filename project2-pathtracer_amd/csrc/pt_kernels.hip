@@ -288,58 +288,63 @@ __device__ __forceinline__ int nearest_hit_culled(const GeomRec *lg, const GeomR
 }
 
 // Many-primitive variant (33..256 primitives).  nearest_hit_culled runs its two exact-test loops once per
-// block of 32 primitives, so a 256-primitive scene pays ~13 mostly empty lock-step rounds per 64-ray group.
-// Here the wave-uniform scan fills eight mask registers (same 2 instructions per primitive), the masks are
-// turned into two packed per-lane index lists (cubes / spheres, 8 bits per entry, up to 8 entries each,
-// nearest candidate first -- ~10 instructions per set bit, no LDS), and the exact loops run ONCE over the
-// lists: ~5 rounds.  A wave in which any lane has more than 8 candidates of a type takes the block-wise
-// path, so the result is always the reference's.
+// block of 32 primitives, so a 256-primitive scene pays ~13 mostly empty lock-step rounds per 64-ray group, and a
+// wave-uniform scan of 256 bounds costs 256 x 22 instructions per group whatever the rays do.  Here the culling is
+// two-level: the host sorts the primitives of each type into spatial clusters of 4..8 members (median splits of
+// the centres); (1) a wave-uniform pass tests the <= 64 cluster boxes and leaves a 64-bit per-lane cluster mask,
+// (2) each lane walks ITS clusters -- cubes first, then spheres, so that the wave stays on one code path -- and
+// tests the members' own bounds through a per-lane gather from the LDS table, appending candidates to two packed
+// per-lane lists (8 bits per entry, up to 8 entries per type, nearest candidate moved to the front).  The exact
+// loops then run ONCE over the lists.  A wave in which any lane has more than 8 candidates of a type takes the
+// block-wise path, so the result is always the reference's.  Cluster boxes are unions of the members' conservative
+// bounds, so a primitive the exact test can hit is always reached.
+#ifndef PT_CLUSTER
+#define PT_CLUSTER 4                                  // preferred members per cluster; the host grows it until <= 64 clusters
+#endif
+constexpr int kClusterMax = 8;
+struct __attribute__((aligned(16))) ClusterRec {      // lives behind the geometry table in LDS, cube clusters first
+    float bmin[3]; int first;                         // first member in the id list
+    float bmax[3]; int count;
+};
+
 template <bool GEOM_LDS>
-__device__ __forceinline__ int nearest_hit_wide(const GeomRec *lg, const GeomRec *__restrict__ gg, int G, f3 o, f3 d,
-                                                float &tbest, f3 &P, f3 &N) {
+__device__ __forceinline__ int nearest_hit_wide(const GeomRec *lg, const GeomRec *__restrict__ gg, int G, int nbc, int nsc,
+                                                f3 o, f3 d, float &tbest, f3 &P, f3 &N) {
     const GeomRec *tab = GEOM_LDS ? lg : gg;
+    const ClusterRec *cl = reinterpret_cast<const ClusterRec *>(lg + G);
+    const unsigned char *members = reinterpret_cast<const unsigned char *>(cl + nbc + nsc);
     const CullRay cr = make_cull_ray(o, d);
-    uint32_t m[8], boxw[8], sphw[8];
-    float near_t[2] = {3.0e38f, 3.0e38f};
-    int near_p[2] = {-1, -1};
-#pragma unroll
-    for (int w = 0; w < 8; ++w) {
-        uint32_t mask = 0u, bb = 0u, sb = 0u;
-        const int base = w * 32;
-        const int n = base >= G ? 0 : ((G - base) < 32 ? (G - base) : 32);
-        for (int j = 0; j < n; ++j) {                     // wave-uniform index: broadcast loads
-            const GeomRec &g = tab[base + j];
-            const int type = g.type;
-            float tn;
-            bool keep;
-            if (type == 1) { bb |= 1u << j; keep = cull_box(g.bmin, g.bmax, cr, tn); }
-            else if (type == 0) { sb |= 1u << j; keep = cull_sphere(g.bmin, g.bmax, cr, tn); }
-            else continue;
-            if (keep) {
-                mask |= 1u << j;
-                const int ty = type == 1 ? 0 : 1;
-                if (tn < near_t[ty]) { near_t[ty] = tn; near_p[ty] = base + j; }
-            }
-        }
-        m[w] = mask; boxw[w] = bb; sphw[w] = sb;
+    // (1) wave-uniform: cluster boxes
+    u64 cm = 0ull;
+    for (int c = 0; c < nbc + nsc; ++c) {
+        float tn;
+        if (cull_box(cl[c].bmin, cl[c].bmax, cr, tn)) cm |= 1ull << c;
     }
-    // masks -> packed lists; entry 0 is kept for the nearest candidate of the type
-    uint32_t lo[2] = {0u, 0u}, hi[2] = {0u, 0u}, cnt[2] = {0u, 0u};
+    // (2) per lane: members of the lane's clusters -> packed candidate lists
+    u64 list[2] = {0ull, 0ull};
+    uint32_t cnt[2] = {0u, 0u}, near_pos[2] = {0u, 0u};
+    float near_t[2] = {3.0e38f, 3.0e38f};
     bool overflow = false;
+    const u64 boxclusters = nbc >= 64 ? ~0ull : ((1ull << nbc) - 1ull);
 #pragma unroll
-    for (int w = 0; w < 8; ++w) {
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            uint32_t mm = m[w] & (pass == 0 ? boxw[w] : sphw[w]);
-            while (mm) {
-                const uint32_t p = (uint32_t)(w * 32 + __builtin_ctz(mm));
-                mm &= mm - 1u;
-                if ((int)p == near_p[pass]) continue;
-                const uint32_t pos = cnt[pass] + 1u;
-                if (pos < 4u) lo[pass] |= p << (8u * pos);
-                else if (pos < 8u) hi[pass] |= p << (8u * (pos - 4u));
-                else overflow = true;
-                cnt[pass] = pos;
+    for (int pass = 0; pass < 2; ++pass) {
+        u64 m = pass == 0 ? (cm & boxclusters) : (cm & ~boxclusters);
+        while (m) {                                       // per-lane trip count; the wave runs until all lanes are done
+            const int c = __builtin_ctzll(m);
+            m &= m - 1ull;
+            const int first = cl[c].first, count = cl[c].count;      // per-lane LDS reads
+#pragma unroll 1
+            for (int k = 0; k < count; ++k) {
+                const uint32_t p = members[first + k];
+                const GeomRec *g = tab + p;               // per-lane gather of the member's own bound
+                float tn;
+                const bool keep = pass == 0 ? cull_box(g->bmin, g->bmax, cr, tn) : cull_sphere(g->bmin, g->bmax, cr, tn);
+                if (keep) {
+                    const uint32_t pos = cnt[pass];
+                    if (pos < 8u) list[pass] |= (u64)p << (8u * pos); else overflow = true;
+                    if (tn < near_t[pass]) { near_t[pass] = tn; near_pos[pass] = pos; }
+                    cnt[pass] = pos + 1u;
+                }
             }
         }
     }
@@ -348,11 +353,17 @@ __device__ __forceinline__ int nearest_hit_wide(const GeomRec *lg, const GeomRec
     int hit = -1;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
-        const bool have = near_p[pass] >= 0;
-        const uint32_t total = have ? cnt[pass] + 1u : 0u;
-        const uint32_t l0 = lo[pass] | (have ? (uint32_t)near_p[pass] : 0u), l1 = hi[pass];
+        // nearest candidate to the front: tested first, its exact hit lets the re-check drop the others
+        u64 L = list[pass];
+        {
+            const uint32_t sh = 8u * near_pos[pass];
+            const u64 e0 = L & 0xFFull, en = (L >> sh) & 0xFFull;
+            L = (L & ~(0xFFull << sh)) | (e0 << sh);
+            L = (L & ~0xFFull) | en;
+        }
+        const uint32_t total = cnt[pass];
         for (uint32_t i = 0; i < total; ++i) {            // per-lane trip count; the wave runs until all lanes are done
-            const int p = (int)(((i < 4u) ? (l0 >> (8u * i)) : (l1 >> (8u * (i - 4u)))) & 0xFFu);
+            const int p = (int)((L >> (8u * i)) & 0xFFull);
             const GeomRec *g = tab + p;                   // per-lane gather
             if (hit >= 0) {                               // entered farther than the best exact hit: cannot win or tie
                 float tn;
@@ -377,7 +388,7 @@ __device__ __forceinline__ int nearest_hit_wide(const GeomRec *lg, const GeomRec
 constexpr uint32_t kCtrlBytes = 64;
 
 __device__ __forceinline__ void stage_tables(char *smem_base, const GeomRec *geoms, int G, const MatRec *mats, int M,
-                                             bool geoms_in_lds, GeomRec *&lg, MatRec *&lm) {
+                                             bool geoms_in_lds, GeomRec *&lg, MatRec *&lm, uint32_t extra_bytes = 0u) {
     char *smem = smem_base + kCtrlBytes;
     uint32_t *dst = reinterpret_cast<uint32_t *>(smem);
     lm = reinterpret_cast<MatRec *>(smem);
@@ -387,7 +398,7 @@ __device__ __forceinline__ void stage_tables(char *smem_base, const GeomRec *geo
     lg = reinterpret_cast<GeomRec *>(smem + ((mwords * 4 + 15) & ~15u));
     if (geoms_in_lds) {
         uint32_t *gdst = reinterpret_cast<uint32_t *>(lg);
-        const uint32_t gwords = (uint32_t)G * (sizeof(GeomRec) / 4);
+        const uint32_t gwords = (uint32_t)G * (sizeof(GeomRec) / 4) + extra_bytes / 4u;    // + cluster table behind the records
         const uint32_t *gsrc = reinterpret_cast<const uint32_t *>(geoms);
         for (uint32_t i = threadIdx.x; i < gwords; i += blockDim.x) gdst[i] = gsrc[i];
     }
@@ -458,11 +469,11 @@ __device__ __forceinline__ bool shade_hit(const MatRec m, f3 P, f3 N, int bounce
 template <bool GEOM_LDS, bool LAST, bool CULL, bool WIDE = false>
 __device__ __forceinline__ bool bounce_ray(const GeomRec *lg, const GeomRec *__restrict__ geoms, const MatRec *lm,
                                            int G, int bounce, uint32_t iteration, float *image, uint32_t pixel,
-                                           f3 &o, f3 &d, f3 &thr, uint32_t &emitted) {
+                                           f3 &o, f3 &d, f3 &thr, uint32_t &emitted, int nbc = 0, int nsc = 0) {
     float t;
     f3 P, N;
     int hit;
-    if (CULL && WIDE) hit = nearest_hit_wide<GEOM_LDS>(lg, geoms, G, o, d, t, P, N);
+    if (CULL && WIDE) hit = nearest_hit_wide<GEOM_LDS>(lg, geoms, G, nbc, nsc, o, d, t, P, N);
     else if (CULL) hit = nearest_hit_culled<GEOM_LDS>(lg, geoms, G, o, d, t, P, N);
     else if (GEOM_LDS) hit = nearest_hit(lg, G, o, d, t, P, N);
     else hit = nearest_hit(geoms, G, o, d, t, P, N);
@@ -685,6 +696,8 @@ struct SegArgs {
     uint32_t bin1_offset;            // binned ordering: bin-1 counts live at cnt[bin1_offset + seg]
     const uint32_t *lights;          // direct_light: indices of the emitting primitives, in index order
     uint32_t nlights;
+    int nbc, nsc;                    // many-primitive variant: cube / sphere clusters behind the geometry table
+    uint32_t cluster_bytes;          //   and the size of that table (clusters + member ids, multiple of 16)
     CamRec cam;
 };
 
@@ -698,7 +711,7 @@ __global__ __launch_bounds__(kBlock, (NEE || WIDE) ? 4 : PT_SEG_WAVES) void k_bo
     if (threadIdx.x < 2) ctrl[threadIdx.x] = 0u;
     GeomRec *lg;
     MatRec *lm;
-    stage_tables(smem, geoms, a.G, mats, a.M, GEOM_LDS, lg, lm);     // ends with __syncthreads()
+    stage_tables(smem, geoms, a.G, mats, a.M, GEOM_LDS, lg, lm, WIDE ? a.cluster_bytes : 0u);     // ends with __syncthreads()
 
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
     const uint32_t wslot = blockIdx.x * kWaves + wave, nslots = gridDim.x * kWaves;
@@ -771,7 +784,7 @@ __global__ __launch_bounds__(kBlock, (NEE || WIDE) ? 4 : PT_SEG_WAVES) void k_bo
                     pixel |= (slot << 24) | (flag << 31);
                 } else {
                     float *acc = a.batch > 1u ? a.planes + (size_t)slot * a.plane_stride : a.image;
-                    alive = bounce_ray<GEOM_LDS, LAST, CULL, WIDE>(lg, geoms, lm, a.G, a.bounce, a.iteration + slot, acc, pixel, o, d, thr, emitted);
+                    alive = bounce_ray<GEOM_LDS, LAST, CULL, WIDE>(lg, geoms, lm, a.G, a.bounce, a.iteration + slot, acc, pixel, o, d, thr, emitted, a.nbc, a.nsc);
                     pixel |= slot << 24;
                 }
             }
@@ -1967,7 +1980,9 @@ struct pt_context {
     uint32_t pix_mask = 0xFFFFFFu;   // pixel bits of the pool's pixel word (all 32 for frames above 2^24 pixels)
     bool empty = false;              // this context owns no row of the frame (row_offset >= H): every call is a no-op
     float *d_planes = nullptr;       // batch_max accumulator planes (W*H*3 floats each)
-    bool wide = false;               // 33..256 primitives in LDS: k_bounce_seg<.., WIDE> (mask registers -> packed candidate lists)
+    bool wide = false;               // 33..256 primitives in LDS: k_bounce_seg<.., WIDE> (two-level cluster culling -> packed candidate lists)
+    int nbc = 0, nsc = 0;            // its cube / sphere clusters, stored behind the GeomRec array of d_geoms
+    uint32_t cluster_bytes = 0;
     // cfg.streams > 1: this context only owns the frame (image) and fans every call out to `subs`, one
     // ordinary context per stream, each rendering every streams-th of this context's rows into that image
     std::vector<pt_context *> subs;
@@ -2423,6 +2438,7 @@ int enqueue_iterations(pt_context *c, uint32_t iteration, uint32_t batch, int st
         a.n_rays = n_rays; a.batch = batch; a.planes = c->d_planes; a.plane_stride = (size_t)c->W * c->H * 3;
         a.bin1_offset = c->nseg + 2u;
         a.lights = c->d_lights; a.nlights = c->nlights;
+        a.nbc = c->nbc; a.nsc = c->nsc; a.cluster_bytes = c->wide ? c->cluster_bytes : 0u;
         const bool last = (stop_after < 0) && (b == D - 1);
         int rc = launch_seg(c, a, last, b == 0);
         if (rc) return rc;
@@ -2729,6 +2745,75 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     // 33..256 primitives with the table in LDS: the mask-register / packed-list variant (PT_WIDE=0 turns it off)
     c->wide = c->cull && c->geom_lds && !c->nee && !c->use_bvh && !c->defer && !c->binned && !c->queue && !have_mesh && c->cfg.mode == 0 && G > 32 && G <= 256;
     if (const char *wv = getenv("PT_WIDE")) if (atoi(wv) == 0) c->wide = false;
+    // two-level culling of the many-primitive variant: clusters of <= kClusterSize primitives of one type
+    std::vector<unsigned char> cluster_blob;
+    c->nbc = c->nsc = 0; c->cluster_bytes = 0;
+    if (c->wide) {
+        std::vector<ClusterRec> recs;
+        std::vector<unsigned char> ids;
+        int csize = PT_CLUSTER;
+        if (const char *cv = getenv("PT_CLUSTER_SIZE")) csize = atoi(cv);
+        if (csize < 1) csize = 1;
+        if (csize > kClusterMax) csize = kClusterMax;
+        for (; csize <= kClusterMax; ++csize) {                // the per-lane cluster mask has 64 bits
+            int nb = 0, ns = 0;
+            for (int i = 0; i < G; ++i) { if (g[i].type == 1) nb++; else if (g[i].type == 0) ns++; }
+            if ((nb + csize - 1) / csize + (ns + csize - 1) / csize <= 64) break;
+        }
+        if (csize > kClusterMax) csize = kClusterMax;
+        for (int pass = 0; pass < 2; ++pass) {
+            const int type = pass == 0 ? 1 : 0;
+            std::vector<int> prim;
+            for (int i = 0; i < G; ++i) if (g[i].type == type) prim.push_back(i);
+            auto lo_of = [&](int i, int k) { return type == 1 ? g[i].bmin[k] : g[i].bmin[k] - g[i].bmax[3]; };
+            auto hi_of = [&](int i, int k) { return type == 1 ? g[i].bmax[k] : g[i].bmin[k] + g[i].bmax[3]; };
+            // recursive median split of the centres along the widest axis, left parts whole numbers of clusters
+            std::vector<std::pair<int, int>> stack{{0, (int)prim.size()}};
+            std::vector<std::pair<int, int>> leaves;
+            while (!stack.empty()) {
+                const std::pair<int, int> r = stack.back();
+                stack.pop_back();
+                const int first = r.first, count = r.second;
+                if (count <= 0) continue;
+                if (count <= csize) { leaves.push_back(r); continue; }
+                int axis = 0;
+                float ext = -1.0f;
+                for (int k = 0; k < 3; ++k) {
+                    float cmin = 3e38f, cmax = -3e38f;
+                    for (int q = first; q < first + count; ++q) { const float cc = lo_of(prim[q], k) + hi_of(prim[q], k); cmin = std::fmin(cmin, cc); cmax = std::fmax(cmax, cc); }
+                    if (cmax - cmin > ext) { ext = cmax - cmin; axis = k; }
+                }
+                int half = ((count / 2 + csize - 1) / csize) * csize;
+                if (half >= count) half = count - csize > 0 ? count - csize : count / 2;
+                std::nth_element(prim.begin() + first, prim.begin() + first + half, prim.begin() + first + count, [&](int x, int y) {
+                    const float cx = lo_of(x, axis) + hi_of(x, axis), cy = lo_of(y, axis) + hi_of(y, axis);
+                    return cx < cy || (cx == cy && x < y);
+                });
+                stack.push_back({first + half, count - half});
+                stack.push_back({first, half});
+            }
+            for (const std::pair<int, int> &lf : leaves) {
+                ClusterRec r;
+                for (int k = 0; k < 3; ++k) { r.bmin[k] = 3e38f; r.bmax[k] = -3e38f; }
+                r.first = (int)ids.size(); r.count = lf.second;
+                for (int q = lf.first; q < lf.first + lf.second; ++q) {
+                    ids.push_back((unsigned char)prim[q]);
+                    for (int k = 0; k < 3; ++k) { r.bmin[k] = std::fmin(r.bmin[k], lo_of(prim[q], k)); r.bmax[k] = std::fmax(r.bmax[k], hi_of(prim[q], k)); }
+                }
+                recs.push_back(r);
+                if (pass == 0) c->nbc++; else c->nsc++;
+            }
+        }
+        if (c->nbc + c->nsc > 64) c->wide = false;            // the per-lane cluster mask has 64 bits
+        else {
+            const size_t idbytes = (ids.size() + 15) & ~(size_t)15;
+            cluster_blob.assign(recs.size() * sizeof(ClusterRec) + idbytes, 0);
+            memcpy(cluster_blob.data(), recs.data(), recs.size() * sizeof(ClusterRec));
+            memcpy(cluster_blob.data() + recs.size() * sizeof(ClusterRec), ids.data(), ids.size());
+            c->cluster_bytes = (uint32_t)cluster_blob.size();
+            c->lds_bytes += c->cluster_bytes;
+        }
+    }
     const void *fns[8] = {
         reinterpret_cast<const void *>(&k_bounce<true, false>), reinterpret_cast<const void *>(&k_bounce<false, false>),
         reinterpret_cast<const void *>(&k_bounce<true, true>), reinterpret_cast<const void *>(&k_bounce<false, true>),
@@ -2829,7 +2914,9 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     HIPCHK(hipMalloc(&c->image_own, (size_t)W * H * 3 * sizeof(float)));
     HIPCHK(hipMemsetAsync(c->image_own, 0, (size_t)W * H * 3 * sizeof(float), c->stream));
     if (!c->image) c->image = c->image_own;
-    HIPCHK(hipMalloc(&c->d_geoms, (size_t)G * sizeof(GeomRec)));
+    HIPCHK(hipMalloc(&c->d_geoms, (size_t)G * sizeof(GeomRec) + cluster_blob.size()));
+    if (!cluster_blob.empty())
+        HIPCHK(hipMemcpy(reinterpret_cast<char *>(c->d_geoms) + (size_t)G * sizeof(GeomRec), cluster_blob.data(), cluster_blob.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc(&c->d_mats, (size_t)M * sizeof(MatRec)));
     HIPCHK(hipMalloc(&c->d_display, (size_t)W * H * sizeof(uchar4)));
     HIPCHK(hipMemcpy(c->d_geoms, g.data(), (size_t)G * sizeof(GeomRec), hipMemcpyHostToDevice));
