@@ -185,8 +185,7 @@ def main():
     ap.add_argument("--chunk-rays", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--merge-floor", type=int, default=0)
-    ap.add_argument("--ordering", type=int, default=1, help="0 = stable compaction (library default), 1 = typed work queues, 2 = binned two-ended compaction, 3 = round 1 sparse-work queue")
-    ap.add_argument("--bvh", type=int, default=0, help="experimental: 1 = per-lane BVH walk, 2 = uniform scan into candidate lists (0 = block-wise culling)")
+    ap.add_argument("--ordering", type=int, default=1, help="0 = stable compaction (library default), 1 = typed work queues (<= 32 primitives)")
     ap.add_argument("--batch", type=int, default=0, help="iterations per launch group (0 = auto, 1 = off)")
     ap.add_argument("--resolution", default="", help="WxH override of the scene RES line (experiments only)")
     ap.add_argument("--culling", type=int, default=0, help="0 = AABB candidate culling (default), 1 = brute force")
@@ -259,7 +258,7 @@ def main():
     accum = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda:%d" % device)
     tracer = pkg.PathTracer(pkg.default_config(device=device, max_depth=depth, row_offset=rank, row_stride=world, streams=S,
                                                geometry_path=args.geometry_path, chunk_rays=args.chunk_rays,
-                                               blocks_per_cu=args.blocks_per_cu, culling=args.culling, merge_floor=args.merge_floor, batch=args.batch, ordering=args.ordering, bvh=args.bvh,
+                                               blocks_per_cu=args.blocks_per_cu, culling=args.culling, merge_floor=args.merge_floor, batch=args.batch, ordering=args.ordering,
                                                compaction=args.compaction, direct_light=args.direct_light, **options))
     tracer.upload(geoms, mats, cam)
     tracer.bind_device_image(accum)
@@ -405,7 +404,7 @@ def main():
             "config": {"workload": desc, "scene": scene_path, "resolution": [W, H], "bounces": depth,
                        "rays_per_step": W * H, "sharding": "rows interleaved over %d GPU(s), 1 RCCL %s per frame" % (world, "gather of the owned rows" if args.exchange == "gather" else "reduce"),
                        "live_ray_bounces_per_step": round(live_per_step),
-                       "compaction": ("segmented, wave-autonomous; " + {0: "stable order (ordering=0)", 1: "typed work queues (ordering=1)", 2: "binned two-ended (ordering=2)", 3: "round-1 sparse-work queue (ordering=3)"}[args.ordering]) if args.compaction == 0 else "global look-back scan",
+                       "compaction": ("segmented, wave-autonomous; " + {0: "stable order (ordering=0)", 1: "typed work queues (ordering=1)"}.get(args.ordering, "stable order")) if args.compaction == 0 else "global look-back scan",
                        "direct_light": bool(args.direct_light), "streams_per_gpu": S,
                        "warmup_passes": "W steps + %d untimed K-step passes (same launch-group shape as the timed passes; until three in a row agree to 1 %%)" % warm_passes},
             "roofline": roof,

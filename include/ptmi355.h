@@ -29,8 +29,9 @@ extern "C" {
 /* 2: pt_config grew by `streams` + reserved[3] (1 ended at `direct_light`); always fill pt_config through
  * pt_config_default() first, so that fields added later keep their defaults
  * 3: + pt_get_rows, pt_gather_rows_peer (the per-frame exchange of a row-sharded render)
- * 4: + pt_mesh, pt_set_meshes, pt_scene_mesh_count, pt_scene_mesh (GEOMTYPE MESH) */
-#define PTMI355_ABI_VERSION 4
+ * 4: + pt_mesh, pt_set_meshes, pt_scene_mesh_count, pt_scene_mesh (GEOMTYPE MESH)
+ * 5: ordering 2 / 3 and bvh 1 / 2 (round-1 experiments, all slower than what replaced them) are gone; the fields stay */
+#define PTMI355_ABI_VERSION 5
 
 typedef enum {
     PT_OK = 0,
@@ -108,26 +109,18 @@ typedef struct {
                                 and the planes are folded into the image in iteration order. */
     int   ordering;          /* 0 = stable: the compacted stream keeps generation order (default)
                                 1 = typed work queues (<= 32 primitives, LDS tables): the unit of work is one exact
-                                    test of a ray against its nearest untested candidate; rays wait on wave-private
-                                    LDS stacks by candidate type and every stage runs on full waves; survivors fill
-                                    the wave's own segments densely (fastest; survivors keep their wave, not their
-                                    segment or order; results identical)
-                                2 = binned: every scattered ray is classified by the culling pass of its NEW
-                                    direction and written to the front (trivial candidate set) or the back of
-                                    its segment; the candidate mask travels with the ray
-                                3 = round 1's sparse-work queue: only rays with non-trivial candidate sets are
-                                    regrouped (kept for comparison) */
-    int   bvh;               /* experimental culling structures for <= 256 primitives (both bit-identical, both
-                                measured SLOWER than the default block-wise culling at 256 primitives, see
-                                DESIGN.md): 1 = per-lane BVH walk (LDS nodes, per-lane stack and candidate
-                                lists), 2 = wave-uniform scan of the bounds into per-lane candidate lists;
-                                0 = off */
+                                    test of a ray against its nearest candidate; rays wait on wave-private LDS stacks
+                                    by candidate type and both stages run on full waves; survivors fill the wave's own
+                                    segments densely (fastest; survivors keep their wave, not their segment or order;
+                                    results identical).  Other values behave like 0. */
+    int   bvh;               /* unused (round-1 experiments, removed); scenes with 33..256 analytic primitives use
+                                two-level cluster culling automatically, meshes carry their own BVH */
     int   direct_light;      /* 1 = next-event estimation: at every diffuse hit one shadow
                                 ray to a point drawn by getRandomPointOnCube / getRandomPointOnSphere
                                 (src/intersections.h:220-286) on a random emitter; emitter hits then add
                                 radiance only for camera rays and after specular events.  Same expectation
                                 as mode 0 without it, far less noise for small lights.  Needs compaction=0,
-                                culling=0, geometry_path=0 (LDS tables); ordering/bvh are ignored. */
+                                culling=0, geometry_path=0 (LDS tables); ordering is ignored. */
     int   streams;           /* 1 = one HIP stream (default).  n > 1: the context shards its rows once more over n
                                 internal contexts, each on its own stream, all rendering into the same image and
                                 all enqueued before any is awaited: the tails of one stream's launches are filled

@@ -39,7 +39,6 @@ constexpr int kBlock = 256;          // 4 waves
 #endif                               // 80 VGPRs, <= 8 B of scratch; measured 4 % faster than 5 (83 VGPRs), 7 spills
 constexpr int kWaves = kBlock / 64;
 constexpr int kFields = 10;          // ox oy oz dx dy dz tr tg tb pixel
-constexpr int kPoolFields = 11;      // + candidate mask (binned ordering only)
 constexpr uint32_t kSpinLimit = 1u << 22;
 
 typedef unsigned long long u64;
@@ -693,7 +692,6 @@ struct SegArgs {
     float *planes;                   // batch > 1: one accumulator plane per in-flight iteration slot
     size_t plane_stride;             //   (floats); folded into the image in iteration order afterwards
     uint32_t bank;                   // counter bank of this launch group (the host alternates 0/1)
-    uint32_t bin1_offset;            // binned ordering: bin-1 counts live at cnt[bin1_offset + seg]
     const uint32_t *lights;          // direct_light: indices of the emitting primitives, in index order
     uint32_t nlights;
     int nbc, nsc;                    // many-primitive variant: cube / sphere clusters behind the geometry table
@@ -807,209 +805,6 @@ __global__ __launch_bounds__(kBlock, (NEE || WIDE) ? 4 : PT_SEG_WAVES) void k_bo
     }
 
     // stats: wave sums -> block sums in LDS -> one fire-and-forget global atomic per block
-    for (int sft = 32; sft > 0; sft >>= 1) emitted += __shfl_down(emitted, sft);
-    if (lane == 0) {
-        if (survivors) atomicAdd(&ctrl[0], survivors);
-        if (emitted) atomicAdd(&ctrl[1], emitted);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (ctrl[0]) atomicAdd(&bank[a.bounce + 1], ctrl[0]);
-        if (ctrl[1]) atomicAdd(&a.sync->emitted, (u64)ctrl[1]);
-    }
-}
-
-// ------------------------------------------------------------------ bounce, sparse-work queue ---
-// Same work as k_bounce_seg with culling, organised so that the exact-test loops run on full waves.
-// Measured on the Cornell box (tools/cullstats.py): per 64-ray group the exact cube loop runs 1.43
-// times at 31 active lanes and the exact sphere loop 0.96 times at 6 active lanes -- the second and
-// the sphere rounds are paid by the whole wave for a handful of rays.  Here a lane whose candidate set
-// is not trivial (a sphere candidate, or more than one cube candidate) does not hold its wave up:
-// its ray (11 dwords incl. the candidate mask) goes to a wave-private LDS ring, the wave finishes
-// the simple lanes (at most ONE exact cube test each), and whenever 64 deferred rays have gathered
-// they are popped and run through the general per-lane loop as one dense group.  A segment's ring is
-// drained before the wave leaves the segment, so every survivor still lands in its own segment --
-// but not in generation order inside it (deterministic, results identical; `ordering` in DESIGN.md).
-constexpr uint32_t kQueueCap = 128;      // entries per wave ring (a power of two >= 2*64 - 1)
-constexpr uint32_t kQueueFields = 11;    // o d thr pixelword mask
-
-template <bool LAST, bool GEN>
-__global__ __launch_bounds__(kBlock, PT_SEG_WAVES) void k_bounce_defer(SegArgs a, const GeomRec *__restrict__ geoms,
-                                                                       const MatRec *__restrict__ mats) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint32_t *ctrl = reinterpret_cast<uint32_t *>(smem);   // [0] survivors, [1] emitted (block sums)
-    if (threadIdx.x < 2) ctrl[threadIdx.x] = 0u;
-    GeomRec *lg;
-    MatRec *lm;
-    stage_tables(smem, geoms, a.G, mats, a.M, true, lg, lm);        // ends with __syncthreads()
-
-    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-    const uint32_t wslot = blockIdx.x * kWaves + wave, nslots = gridDim.x * kWaves;
-    const size_t cap = a.cap;
-    const uint32_t S = a.seg_slots;
-    uint32_t emitted = 0u, survivors = 0u;
-    float *ring = reinterpret_cast<float *>(smem + tables_bytes(a.G, a.M, true)) + (size_t)wave * kQueueCap * kQueueFields;
-
-    uint32_t *bank = a.bank ? a.sync->counts_b : a.sync->counts;
-    if (GEN && blockIdx.x == 0 && threadIdx.x < 72) {
-        uint32_t *other = a.bank ? a.sync->counts : a.sync->counts_b;
-        a.sync->totals[threadIdx.x] += other[threadIdx.x];
-        other[threadIdx.x] = 0u;
-        if (threadIdx.x == 0) bank[0] = a.n_rays;
-    }
-
-    // primitive types as bit sets (wave-uniform; G <= 32 on this path)
-    uint32_t boxbits = 0u, sphbits = 0u;
-    for (int j = 0; j < a.G; ++j) {
-        const int type = lg[j].type;
-        if (type == 1) boxbits |= 1u << j;
-        else if (type == 0) sphbits |= 1u << j;
-    }
-
-    uint32_t qhead = 0u, qcount = 0u;                     // wave-uniform ring state
-    for (uint32_t seg = wslot; seg < a.nseg_out; seg += nslots) {
-        const uint32_t sa = a.merge ? 2u * seg : seg;
-        uint32_t na, nb;
-        if (GEN) {
-            const uint32_t f0 = sa * S, f1 = f0 + S;
-            na = f0 >= a.n_rays ? 0u : (a.n_rays - f0 < S ? a.n_rays - f0 : S);
-            nb = (!a.merge || f1 >= a.n_rays) ? 0u : (a.n_rays - f1 < S ? a.n_rays - f1 : S);
-        } else {
-            na = a.cnt_in[sa];
-            nb = (a.merge && sa + 1u < a.nseg_in) ? a.cnt_in[sa + 1u] : 0u;
-        }
-        const uint32_t n = na + nb;
-        const uint32_t base = sa * S;
-        uint32_t running = 0u, g = 0u;
-        for (;;) {
-            const bool fresh_left = g < n;
-            const bool from_q = qcount >= 64u || (!fresh_left && qcount > 0u);
-            if (!from_q && !fresh_left) break;
-            bool valid;
-            f3 o = mk(0, 0, 0), d = mk(0, 0, 0), thr = mk(0, 0, 0);
-            uint32_t pv = 0u, mask = 0u;
-            if (from_q) {
-                const uint32_t cnt = qcount < 64u ? qcount : 64u;
-                valid = lane < cnt;
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (valid) {
-                    const float *q = ring + ((qhead + lane) & (kQueueCap - 1u));
-                    o = mk(q[0 * kQueueCap], q[1 * kQueueCap], q[2 * kQueueCap]);
-                    d = mk(q[3 * kQueueCap], q[4 * kQueueCap], q[5 * kQueueCap]);
-                    thr = mk(q[6 * kQueueCap], q[7 * kQueueCap], q[8 * kQueueCap]);
-                    pv = __float_as_uint(q[9 * kQueueCap]);
-                    mask = __float_as_uint(q[10 * kQueueCap]);
-                }
-                qhead = (qhead + cnt) & (kQueueCap - 1u);
-                qcount -= cnt;
-            } else {
-                const uint32_t k = g + lane;
-                g += 64u;
-                valid = k < n;
-                if (valid) {
-                    if (GEN) {
-                        const uint32_t gid = base + (k < na ? k : k - na + S);
-                        const uint32_t slot = a.batch > 1u ? gid / a.n_own : 0u;
-                        const uint32_t local = gid - slot * a.n_own;
-                        const uint32_t W = (uint32_t)a.cam.W;
-                        const uint32_t lr = local / W, x = local - lr * W;
-                        const uint32_t pixel = (lr * (uint32_t)a.cam.row_stride + (uint32_t)a.cam.row_offset) * W + x;
-                        camera_ray(a.cam, pixel, a.iteration + slot, o, d);
-                        thr = mk(1.0f, 1.0f, 1.0f);
-                        pv = pixel | (slot << 24);
-                    } else {
-                        const uint32_t idx = base + (k < na ? k : k - na + S);
-                        const float *in = a.in;
-                        o = mk(in[idx], (in + cap)[idx], (in + 2 * cap)[idx]);
-                        d = mk((in + 3 * cap)[idx], (in + 4 * cap)[idx], (in + 5 * cap)[idx]);
-                        thr = mk((in + 6 * cap)[idx], (in + 7 * cap)[idx], (in + 8 * cap)[idx]);
-                        pv = reinterpret_cast<const uint32_t *>(in + 9 * cap)[idx];
-                    }
-                }
-                // (A) conservative candidate mask, wave-uniform primitive index
-                const CullRay cr = make_cull_ray(o, d);
-                for (int j = 0; j < a.G; ++j) {
-                    float tn;
-                    const GeomRec &gr = lg[j];
-                    const int type = gr.type;
-                    bool keep = false;
-                    if (type == 1) keep = cull_box(gr.bmin, gr.bmax, cr, tn);
-                    else if (type == 0) keep = cull_sphere(gr.bmin, gr.bmax, cr, tn);
-                    if (keep) mask |= 1u << j;
-                }
-                if (!valid) mask = 0u;
-                // lanes with a non-trivial candidate set step aside
-                const uint32_t bm = mask & boxbits;
-                const bool complex = valid && ((mask & sphbits) != 0u || (bm & (bm - 1u)) != 0u);
-                const u64 cb = __ballot(complex);
-                if (cb) {
-                    if (complex) {
-                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(cb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cb, 0u));
-                        float *q = ring + ((qhead + qcount + rank) & (kQueueCap - 1u));
-                        q[0 * kQueueCap] = o.x; q[1 * kQueueCap] = o.y; q[2 * kQueueCap] = o.z;
-                        q[3 * kQueueCap] = d.x; q[4 * kQueueCap] = d.y; q[5 * kQueueCap] = d.z;
-                        q[6 * kQueueCap] = thr.x; q[7 * kQueueCap] = thr.y; q[8 * kQueueCap] = thr.z;
-                        q[9 * kQueueCap] = __uint_as_float(pv);
-                        q[10 * kQueueCap] = __uint_as_float(mask);
-                    }
-                    qcount += (uint32_t)__popcll(cb);
-                    // the ring hands rays from one lane to another: order the stores before any later pop
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                }
-                valid = valid && !complex;
-            }
-
-            // (B) exact tests on the lane's own candidates: cubes, then spheres, index order, later
-            // candidates re-checked against the best hit; ties to the lower index (reference loop order)
-            bool alive = false;
-            const uint32_t slot = a.batch > 1u ? pv >> 24 : 0u, pixel = pv & a.pix_mask;
-            if (valid) {
-                float best = 100000000000000000.0f;
-                int hit = -1;
-                f3 P = mk(0, 0, 0), N = mk(0, 0, 0);
-                const CullRay cr = make_cull_ray(o, d);
-                for (int pass = 0; pass < 2; ++pass) {
-                    uint32_t m = mask & (pass == 0 ? boxbits : sphbits);
-                    while (m) {
-                        const int j = __builtin_ctz(m);
-                        m &= m - 1u;
-                        const GeomRec *gr = lg + j;
-                        if (hit >= 0) {
-                            float tn;
-                            if (pass == 0) (void)cull_box(gr->bmin, gr->bmax, cr, tn);
-                            else (void)cull_sphere(gr->bmin, gr->bmax, cr, tn);
-                            if (tn - gr->slack > best) continue;
-                        }
-                        f3 p, nn;
-                        const float depth = pass == 0 ? box_test(gr->inv, gr->xf, gr->inside_hits, o, d, p, nn)
-                                                      : sphere_test(gr->inv, gr->xf, o, d, p, nn);
-                        if (depth > -PT_EPSILON && (depth < best || (depth == best && j < hit))) {
-                            best = depth; hit = j; P = p; N = nn;
-                        }
-                    }
-                }
-                if (hit >= 0) {
-                    float *acc = a.batch > 1u ? a.planes + (size_t)slot * a.plane_stride : a.image;
-                    alive = shade_hit<LAST>(lm[lg[hit].mat], P, N, a.bounce, a.iteration + slot, acc, pixel, o, d, thr, emitted);
-                }
-            }
-            const u64 ballot = __ballot(alive);
-            if (!LAST && alive) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
-                const uint32_t oi = base + running + rank;
-                float *out = a.out;
-                out[oi] = o.x; (out + cap)[oi] = o.y; (out + 2 * cap)[oi] = o.z;
-                (out + 3 * cap)[oi] = d.x; (out + 4 * cap)[oi] = d.y; (out + 5 * cap)[oi] = d.z;
-                (out + 6 * cap)[oi] = thr.x; (out + 7 * cap)[oi] = thr.y; (out + 8 * cap)[oi] = thr.z;
-                reinterpret_cast<uint32_t *>(out + 9 * cap)[oi] = pv;
-            }
-            running += (uint32_t)__popcll(ballot);
-        }
-        if (!LAST && lane == 0) a.cnt_out[seg] = running;
-        survivors += running;
-    }
-
     for (int sft = 32; sft > 0; sft >>= 1) emitted += __shfl_down(emitted, sft);
     if (lane == 0) {
         if (survivors) atomicAdd(&ctrl[0], survivors);
@@ -1401,415 +1196,6 @@ __global__ __launch_bounds__(kBlock, PT_Q_WAVES) void k_bounce_q(SegArgs a, cons
     }
 }
 
-// ------------------------------------------------------------------ bounce, binned ordering -----
-// `ordering = 2`.  The sparse-work queue regroups rays AFTER they turned out to need several exact
-// tests; this variant sorts them BEFORE: when a ray is scattered, its NEW direction is run through the
-// conservative culling pass right away, the candidate mask travels with the ray (11th pool field) and
-// the survivor is written to the FRONT of its segment if the mask is trivial (no sphere candidate, at
-// most one cube candidate) and to the BACK otherwise (two-ended compaction, counts c0 / c1).  The next
-// bounce reads the two runs as two dense lists: front groups need exactly one exact cube test per
-// lane, back groups run the general loop with all lanes busy.  Same number of culling passes per ray
-// as before (one per bounce, just moved to the producer), no LDS ring, no partly filled drain groups.
-// Survivors keep their segment, not their order inside it; results identical.
-__device__ __forceinline__ uint32_t cull_mask(const GeomRec *lg, int G, f3 o, f3 d) {
-    const CullRay cr = make_cull_ray(o, d);
-    uint32_t mask = 0u;
-    for (int j = 0; j < G; ++j) {
-        float tn;
-        const GeomRec &gr = lg[j];
-        const int type = gr.type;
-        bool keep = false;
-        if (type == 1) keep = cull_box(gr.bmin, gr.bmax, cr, tn);
-        else if (type == 0) keep = cull_sphere(gr.bmin, gr.bmax, cr, tn);
-        if (keep) mask |= 1u << j;
-    }
-    return mask;
-}
-
-template <bool LAST, bool GEN>
-__global__ __launch_bounds__(kBlock, PT_SEG_WAVES) void k_bounce_bin(SegArgs a, const GeomRec *__restrict__ geoms,
-                                                                     const MatRec *__restrict__ mats) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint32_t *ctrl = reinterpret_cast<uint32_t *>(smem);
-    if (threadIdx.x < 2) ctrl[threadIdx.x] = 0u;
-    GeomRec *lg;
-    MatRec *lm;
-    stage_tables(smem, geoms, a.G, mats, a.M, true, lg, lm);
-
-    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-    const uint32_t wslot = blockIdx.x * kWaves + wave, nslots = gridDim.x * kWaves;
-    const size_t cap = a.cap;
-    const uint32_t S = a.seg_slots;
-    uint32_t emitted = 0u, survivors = 0u;
-    uint32_t *bank = a.bank ? a.sync->counts_b : a.sync->counts;
-    if (GEN && blockIdx.x == 0 && threadIdx.x < 72) {
-        uint32_t *other = a.bank ? a.sync->counts : a.sync->counts_b;
-        a.sync->totals[threadIdx.x] += other[threadIdx.x];
-        other[threadIdx.x] = 0u;
-        if (threadIdx.x == 0) bank[0] = a.n_rays;
-    }
-    uint32_t boxbits = 0u, sphbits = 0u;
-    for (int j = 0; j < a.G; ++j) {
-        const int type = lg[j].type;
-        if (type == 1) boxbits |= 1u << j;
-        else if (type == 0) sphbits |= 1u << j;
-    }
-
-    for (uint32_t seg = wslot; seg < a.nseg_out; seg += nslots) {
-        const uint32_t base = seg * S;
-        uint32_t c0, c1;
-        if (GEN) {
-            c0 = base >= a.n_rays ? 0u : (a.n_rays - base < S ? a.n_rays - base : S);
-            c1 = 0u;
-        } else {
-            c0 = a.cnt_in[seg];
-            c1 = a.cnt_in[a.bin1_offset + seg];
-        }
-        uint32_t run0 = 0u, run1 = 0u;
-        for (int list = 0; list < 2; ++list) {
-            const uint32_t n = list == 0 ? c0 : c1;
-            for (uint32_t g = 0; g < n; g += 64u) {
-                const uint32_t k = g + lane;
-                const bool valid = k < n;
-                f3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(0, 0, 0);
-                uint32_t pv = 0u, mask = 0u;
-                if (valid) {
-                    if (GEN) {
-                        const uint32_t gid = base + k;
-                        const uint32_t slot = a.batch > 1u ? gid / a.n_own : 0u;
-                        const uint32_t local = gid - slot * a.n_own;
-                        const uint32_t W = (uint32_t)a.cam.W;
-                        const uint32_t lr = local / W, x = local - lr * W;
-                        const uint32_t pixel = (lr * (uint32_t)a.cam.row_stride + (uint32_t)a.cam.row_offset) * W + x;
-                        camera_ray(a.cam, pixel, a.iteration + slot, o, d);
-                        thr = mk(1.0f, 1.0f, 1.0f);
-                        pv = pixel | (slot << 24);
-                    } else {
-                        const uint32_t idx = list == 0 ? base + k : base + S - 1u - k;
-                        const float *in = a.in;
-                        o = mk(in[idx], (in + cap)[idx], (in + 2 * cap)[idx]);
-                        d = mk((in + 3 * cap)[idx], (in + 4 * cap)[idx], (in + 5 * cap)[idx]);
-                        thr = mk((in + 6 * cap)[idx], (in + 7 * cap)[idx], (in + 8 * cap)[idx]);
-                        pv = reinterpret_cast<const uint32_t *>(in + 9 * cap)[idx];
-                        mask = reinterpret_cast<const uint32_t *>(in + 10 * cap)[idx];
-                    }
-                }
-                if (GEN) mask = valid ? cull_mask(lg, a.G, o, d) : 0u;
-                const uint32_t slot = a.batch > 1u ? pv >> 24 : 0u, pixel = pv & a.pix_mask;
-
-                bool alive = false;
-                if (valid) {
-                    float best = 100000000000000000.0f;
-                    int hit = -1;
-                    f3 P = mk(0, 0, 0), N = mk(0, 0, 0);
-                    const CullRay cr = make_cull_ray(o, d);
-                    for (int pass = 0; pass < 2; ++pass) {
-                        uint32_t m = mask & (pass == 0 ? boxbits : sphbits);
-                        while (m) {
-                            const int j = __builtin_ctz(m);
-                            m &= m - 1u;
-                            const GeomRec *gr = lg + j;
-                            if (hit >= 0) {
-                                float tn;
-                                if (pass == 0) (void)cull_box(gr->bmin, gr->bmax, cr, tn);
-                                else (void)cull_sphere(gr->bmin, gr->bmax, cr, tn);
-                                if (tn - gr->slack > best) continue;
-                            }
-                            f3 pp, nn;
-                            const float depth = pass == 0 ? box_test(gr->inv, gr->xf, gr->inside_hits, o, d, pp, nn)
-                                                          : sphere_test(gr->inv, gr->xf, o, d, pp, nn);
-                            if (depth > -PT_EPSILON && (depth < best || (depth == best && j < hit))) {
-                                best = depth; hit = j; P = pp; N = nn;
-                            }
-                        }
-                    }
-                    if (hit >= 0) {
-                        float *acc = a.batch > 1u ? a.planes + (size_t)slot * a.plane_stride : a.image;
-                        alive = shade_hit<LAST>(lm[lg[hit].mat], P, N, a.bounce, a.iteration + slot, acc, pixel, o, d, thr, emitted);
-                    }
-                }
-                if (LAST) {
-                    run0 += (uint32_t)__popcll(__ballot(alive));
-                } else {
-                    // classify the NEW ray for the next bounce, then two-ended compaction
-                    uint32_t nmask = 0u;
-                    if (alive) nmask = cull_mask(lg, a.G, o, d);
-                    const uint32_t nb = nmask & boxbits;
-                    const bool complex = alive && ((nmask & sphbits) != 0u || (nb & (nb - 1u)) != 0u);
-                    const u64 b0 = __ballot(alive && !complex), b1 = __ballot(complex);
-                    if (alive) {
-                        const u64 bb = complex ? b1 : b0;
-                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bb, 0u));
-                        const uint32_t oi = complex ? base + S - 1u - (run1 + rank) : base + run0 + rank;
-                        float *out = a.out;
-                        out[oi] = o.x; (out + cap)[oi] = o.y; (out + 2 * cap)[oi] = o.z;
-                        (out + 3 * cap)[oi] = d.x; (out + 4 * cap)[oi] = d.y; (out + 5 * cap)[oi] = d.z;
-                        (out + 6 * cap)[oi] = thr.x; (out + 7 * cap)[oi] = thr.y; (out + 8 * cap)[oi] = thr.z;
-                        reinterpret_cast<uint32_t *>(out + 9 * cap)[oi] = pv;
-                        reinterpret_cast<uint32_t *>(out + 10 * cap)[oi] = nmask;
-                    }
-                    run0 += (uint32_t)__popcll(b0);
-                    run1 += (uint32_t)__popcll(b1);
-                }
-            }
-        }
-        if (!LAST && lane == 0) { a.cnt_out[seg] = run0; a.cnt_out[a.bin1_offset + seg] = run1; }
-        survivors += run0 + run1;
-    }
-
-    for (int sft = 32; sft > 0; sft >>= 1) emitted += __shfl_down(emitted, sft);
-    if (lane == 0) {
-        if (survivors) atomicAdd(&ctrl[0], survivors);
-        if (emitted) atomicAdd(&ctrl[1], emitted);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (ctrl[0]) atomicAdd(&bank[a.bounce + 1], ctrl[0]);
-        if (ctrl[1]) atomicAdd(&a.sync->emitted, (u64)ctrl[1]);
-    }
-}
-
-// ------------------------------------------------------------------ bounce, BVH culling ---------
-// Many-primitive scenes (33..256 primitives, BASELINE configs[3]): the wave-uniform culling pass of
-// nearest_hit_culled costs ~20 instructions per primitive per ray (5 000 at G = 256).  Here the
-// conservative bounds are organised as a binary BVH (median split, <= 4 primitives per leaf, built on
-// the host at upload) held in LDS next to a 48-byte bound record per primitive; every lane walks it
-// with its own 16-entry stack (LDS, one byte per entry) and appends the primitives whose own bound the
-// ray enters to two per-lane candidate lists (cubes / spheres, 32 one-byte ids each, LDS).  The exact
-// pass then runs list position j of every lane together -- nearest candidate first, later ones
-// re-checked against the best hit -- fetching the matrices from global memory with a per-lane index
-// (the full 144-byte records of 256 primitives would take 37 KB of LDS per block).  A lane whose list
-// overflows makes its wave fall back to the brute-force loop, so the result is always the reference's.
-struct BvhNode {            // 32 B; leaf: a = ~first (negative), b = count; inner: a, b = children
-    float bmin[3]; int a;
-    float bmax[3]; int b;
-};
-struct BoundRec {           // 48 B per primitive (same conservative bound as GeomRec.bmin/bmax)
-    float bmin[4];
-    float bmax[4];
-    int type; float slack; int pad[2];
-};
-constexpr uint32_t kBvhStack = 16, kBvhList = 32;
-
-struct BvhArgs {
-    const BvhNode *nodes; int nnodes;
-    const BoundRec *bounds;
-    const unsigned char *order;   // leaf ranges index into this permutation of the primitives
-    int walk;                     // 1 = per-lane BVH walk, 0 = wave-uniform loop over the bound records
-};
-
-__host__ __device__ inline uint32_t bvh_lds_bytes(int G, int M, int nnodes) {
-    uint32_t b = kCtrlBytes + (((uint32_t)M * sizeof(MatRec) + 15) & ~15u);
-    b += (uint32_t)nnodes * sizeof(BvhNode) + (uint32_t)G * sizeof(BoundRec) + (((uint32_t)G + 15) & ~15u);
-    b += kBlock * (kBvhStack + 2 * kBvhList);
-    return (b + 15) & ~15u;
-}
-
-template <bool LAST, bool GEN>
-__global__ __launch_bounds__(kBlock, PT_SEG_WAVES) void k_bounce_bvh(SegArgs a, BvhArgs bv, const GeomRec *__restrict__ geoms,
-                                                                     const MatRec *__restrict__ mats) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint32_t *ctrl = reinterpret_cast<uint32_t *>(smem);
-    if (threadIdx.x < 2) ctrl[threadIdx.x] = 0u;
-    // LDS: ctrl | materials | nodes | bound records | order | per-thread stack + lists
-    MatRec *lm = reinterpret_cast<MatRec *>(smem + kCtrlBytes);
-    char *cur = smem + kCtrlBytes + (((uint32_t)a.M * sizeof(MatRec) + 15) & ~15u);
-    BvhNode *ln = reinterpret_cast<BvhNode *>(cur); cur += (size_t)bv.nnodes * sizeof(BvhNode);
-    BoundRec *lb = reinterpret_cast<BoundRec *>(cur); cur += (size_t)a.G * sizeof(BoundRec);
-    unsigned char *lo = reinterpret_cast<unsigned char *>(cur); cur += ((uint32_t)a.G + 15) & ~15u;
-    unsigned char *stack = reinterpret_cast<unsigned char *>(cur) + (size_t)threadIdx.x * kBvhStack;
-    unsigned char *lists = reinterpret_cast<unsigned char *>(cur) + (size_t)kBlock * kBvhStack + (size_t)threadIdx.x * 2 * kBvhList;
-    {
-        uint32_t *d0 = reinterpret_cast<uint32_t *>(lm);
-        const uint32_t *s0 = reinterpret_cast<const uint32_t *>(mats);
-        for (uint32_t i = threadIdx.x; i < (uint32_t)a.M * (sizeof(MatRec) / 4); i += kBlock) d0[i] = s0[i];
-        uint32_t *d1 = reinterpret_cast<uint32_t *>(ln);
-        const uint32_t *s1 = reinterpret_cast<const uint32_t *>(bv.nodes);
-        for (uint32_t i = threadIdx.x; i < (uint32_t)bv.nnodes * (sizeof(BvhNode) / 4); i += kBlock) d1[i] = s1[i];
-        uint32_t *d2 = reinterpret_cast<uint32_t *>(lb);
-        const uint32_t *s2 = reinterpret_cast<const uint32_t *>(bv.bounds);
-        for (uint32_t i = threadIdx.x; i < (uint32_t)a.G * (sizeof(BoundRec) / 4); i += kBlock) d2[i] = s2[i];
-        for (uint32_t i = threadIdx.x; i < (uint32_t)a.G; i += kBlock) lo[i] = bv.order[i];
-    }
-    __syncthreads();
-
-    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-    const uint32_t wslot = blockIdx.x * kWaves + wave, nslots = gridDim.x * kWaves;
-    const size_t cap = a.cap;
-    const uint32_t S = a.seg_slots;
-    uint32_t emitted = 0u, survivors = 0u;
-    uint32_t *bank = a.bank ? a.sync->counts_b : a.sync->counts;
-    if (GEN && blockIdx.x == 0 && threadIdx.x < 72) {
-        uint32_t *other = a.bank ? a.sync->counts : a.sync->counts_b;
-        a.sync->totals[threadIdx.x] += other[threadIdx.x];
-        other[threadIdx.x] = 0u;
-        if (threadIdx.x == 0) bank[0] = a.n_rays;
-    }
-
-    for (uint32_t seg = wslot; seg < a.nseg_out; seg += nslots) {
-        const uint32_t sa = a.merge ? 2u * seg : seg;
-        uint32_t na, nb;
-        if (GEN) {
-            const uint32_t f0 = sa * S, f1 = f0 + S;
-            na = f0 >= a.n_rays ? 0u : (a.n_rays - f0 < S ? a.n_rays - f0 : S);
-            nb = (!a.merge || f1 >= a.n_rays) ? 0u : (a.n_rays - f1 < S ? a.n_rays - f1 : S);
-        } else {
-            na = a.cnt_in[sa];
-            nb = (a.merge && sa + 1u < a.nseg_in) ? a.cnt_in[sa + 1u] : 0u;
-        }
-        const uint32_t n = na + nb;
-        const uint32_t base = sa * S;
-        uint32_t running = 0u;
-        for (uint32_t g = 0; g < n; g += 64u) {
-            const uint32_t k = g + lane;
-            const bool valid = k < n;
-            bool alive = false;
-            f3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(0, 0, 0);
-            uint32_t pv = 0u;
-            if (valid) {
-                if (GEN) {
-                    const uint32_t gid = base + (k < na ? k : k - na + S);
-                    const uint32_t slot = a.batch > 1u ? gid / a.n_own : 0u;
-                    const uint32_t local = gid - slot * a.n_own;
-                    const uint32_t W = (uint32_t)a.cam.W;
-                    const uint32_t lr = local / W, x = local - lr * W;
-                    const uint32_t pixel = (lr * (uint32_t)a.cam.row_stride + (uint32_t)a.cam.row_offset) * W + x;
-                    camera_ray(a.cam, pixel, a.iteration + slot, o, d);
-                    thr = mk(1.0f, 1.0f, 1.0f);
-                    pv = pixel | (slot << 24);
-                } else {
-                    const uint32_t idx = base + (k < na ? k : k - na + S);
-                    const float *in = a.in;
-                    o = mk(in[idx], (in + cap)[idx], (in + 2 * cap)[idx]);
-                    d = mk((in + 3 * cap)[idx], (in + 4 * cap)[idx], (in + 5 * cap)[idx]);
-                    thr = mk((in + 6 * cap)[idx], (in + 7 * cap)[idx], (in + 8 * cap)[idx]);
-                    pv = reinterpret_cast<const uint32_t *>(in + 9 * cap)[idx];
-                }
-            }
-            const uint32_t slot = a.batch > 1u ? pv >> 24 : 0u, pixel = pv & a.pix_mask;
-
-            // (A) per-lane BVH walk -> candidate lists
-            const CullRay cr = make_cull_ray(o, d);
-            uint32_t cnt0 = 0u, cnt1 = 0u, near0 = 0u, near1 = 0u;     // list lengths, position of the nearest entry
-            float nt0 = 3.0e38f, nt1 = 3.0e38f;
-            bool overflow = false;
-            if (bv.walk == 0) {
-                // flat variant: wave-uniform loop over all bound records (broadcast LDS reads, no divergence),
-                // candidates appended to the same per-lane lists
-                for (int p = 0; p < a.G; ++p) {
-                    const BoundRec &br = lb[p];
-                    float tp;
-                    if (br.type == 1) {
-                        if (valid && cull_box(br.bmin, br.bmax, cr, tp)) {
-                            if (cnt0 < kBvhList) { lists[cnt0] = (unsigned char)p; if (tp < nt0) { nt0 = tp; near0 = cnt0; } cnt0++; } else overflow = true;
-                        }
-                    } else if (br.type == 0) {
-                        if (valid && cull_sphere(br.bmin, br.bmax, cr, tp)) {
-                            if (cnt1 < kBvhList) { lists[kBvhList + cnt1] = (unsigned char)p; if (tp < nt1) { nt1 = tp; near1 = cnt1; } cnt1++; } else overflow = true;
-                        }
-                    }
-                }
-            } else if (valid) {
-                uint32_t node = 0u, sp = 0u;
-                for (;;) {
-                    const BvhNode nd = ln[node];
-                    float tn;
-                    if (cull_box(nd.bmin, nd.bmax, cr, tn)) {
-                        if (nd.a >= 0) {                              // inner node: descend left, remember right
-                            if (sp < kBvhStack) stack[sp++] = (unsigned char)nd.b; else overflow = true;
-                            node = (uint32_t)nd.a;
-                            continue;
-                        }
-                        const uint32_t first = (uint32_t)~nd.a;
-                        for (int i = 0; i < nd.b; ++i) {
-                            const uint32_t p = lo[first + i];
-                            const BoundRec &br = lb[p];
-                            float tp;
-                            if (br.type == 1) {
-                                if (cull_box(br.bmin, br.bmax, cr, tp)) {
-                                    if (cnt0 < kBvhList) { lists[cnt0] = (unsigned char)p; if (tp < nt0) { nt0 = tp; near0 = cnt0; } cnt0++; } else overflow = true;
-                                }
-                            } else if (br.type == 0) {
-                                if (cull_sphere(br.bmin, br.bmax, cr, tp)) {
-                                    if (cnt1 < kBvhList) { lists[kBvhList + cnt1] = (unsigned char)p; if (tp < nt1) { nt1 = tp; near1 = cnt1; } cnt1++; } else overflow = true;
-                                }
-                            }
-                        }
-                    }
-                    if (sp == 0u) break;
-                    node = stack[--sp];
-                }
-            }
-            if (valid) {
-                // nearest candidate to the front of its list
-                if (cnt0 > 1u && near0 != 0u) { const unsigned char t0 = lists[0]; lists[0] = lists[near0]; lists[near0] = t0; }
-                if (cnt1 > 1u && near1 != 0u) { const unsigned char t1 = lists[kBvhList]; lists[kBvhList] = lists[kBvhList + near1]; lists[kBvhList + near1] = t1; }
-            }
-
-            // (B) exact tests, list position j of every lane together
-            if (valid) {
-                float best = 100000000000000000.0f;
-                int hit = -1;
-                f3 P = mk(0, 0, 0), N = mk(0, 0, 0);
-                if (__any(overflow)) {                               // rare: this wave takes the reference loop
-                    float t;
-                    hit = nearest_hit(geoms, a.G, o, d, t, P, N);
-                } else {
-                    for (int pass = 0; pass < 2; ++pass) {
-                        const uint32_t cnt = pass == 0 ? cnt0 : cnt1;
-                        const unsigned char *lst = lists + pass * kBvhList;
-                        for (uint32_t j = 0; j < cnt; ++j) {
-                            const int p = lst[j];
-                            if (hit >= 0) {
-                                const BoundRec &br = lb[p];
-                                float tn;
-                                if (pass == 0) (void)cull_box(br.bmin, br.bmax, cr, tn);
-                                else (void)cull_sphere(br.bmin, br.bmax, cr, tn);
-                                if (tn - br.slack > best) continue;
-                            }
-                            const GeomRec *gr = geoms + p;                // per-lane gather from global (L1/L2)
-                            f3 pp, nn;
-                            const float depth = pass == 0 ? box_test(gr->inv, gr->xf, gr->inside_hits, o, d, pp, nn)
-                                                          : sphere_test(gr->inv, gr->xf, o, d, pp, nn);
-                            if (depth > -PT_EPSILON && (depth < best || (depth == best && p < hit))) {
-                                best = depth; hit = p; P = pp; N = nn;
-                            }
-                        }
-                    }
-                }
-                if (hit >= 0) {
-                    float *acc = a.batch > 1u ? a.planes + (size_t)slot * a.plane_stride : a.image;
-                    alive = shade_hit<LAST>(lm[geoms[hit].mat], P, N, a.bounce, a.iteration + slot, acc, pixel, o, d, thr, emitted);
-                }
-            }
-            const u64 ballot = __ballot(alive);
-            if (!LAST && alive) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
-                const uint32_t oi = base + running + rank;
-                float *out = a.out;
-                out[oi] = o.x; (out + cap)[oi] = o.y; (out + 2 * cap)[oi] = o.z;
-                (out + 3 * cap)[oi] = d.x; (out + 4 * cap)[oi] = d.y; (out + 5 * cap)[oi] = d.z;
-                (out + 6 * cap)[oi] = thr.x; (out + 7 * cap)[oi] = thr.y; (out + 8 * cap)[oi] = thr.z;
-                reinterpret_cast<uint32_t *>(out + 9 * cap)[oi] = pv;
-            }
-            running += (uint32_t)__popcll(ballot);
-        }
-        if (!LAST && lane == 0) a.cnt_out[seg] = running;
-        survivors += running;
-    }
-
-    for (int sft = 32; sft > 0; sft >>= 1) emitted += __shfl_down(emitted, sft);
-    if (lane == 0) {
-        if (survivors) atomicAdd(&ctrl[0], survivors);
-        if (emitted) atomicAdd(&ctrl[1], emitted);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (ctrl[0]) atomicAdd(&bank[a.bounce + 1], ctrl[0]);
-        if (ctrl[1]) atomicAdd(&a.sync->emitted, (u64)ctrl[1]);
-    }
-}
-
 // ------------------------------------------------------------------ fold (batched iterations) ---
 // image[p] = (((image[p] + plane_0[p]) + plane_1[p]) + ...) in iteration order -- the same sum, in the
 // same order, as rendering the iterations one after the other -- and clears the planes for the next
@@ -1953,7 +1339,6 @@ struct pt_context {
     uint32_t max_chunks = 0, rpt = 3, status_words = 0;
     bool seg_mode = true;            // wave-autonomous segmented compaction (cfg.compaction == 0)
     bool cull = true;                // AABB candidate culling in front of the exact tests (cfg.culling == 0)
-    bool defer = false;              // sparse-work queue kernel (cfg.ordering == 3: round 1's ring of complex rays; LDS geometry, G <= 32)
     bool queue = false;              // typed work-queue kernel (cfg.ordering == 1; LDS geometry, G <= 32, no merging)
     FaceFrame *d_frames = nullptr;   // [G][3] shading frames of the box primitives (k_bounce_q)
     CullRec *d_cull = nullptr;       // bounds for its culling pass, cubes first
@@ -1962,10 +1347,6 @@ struct pt_context {
     struct HostMesh { int geom_index; std::vector<float> v; std::vector<int> idx; };
     std::vector<HostMesh> meshes;
     std::vector<void *> d_mesh_blobs;
-    bool binned = false;             // two-ended binned compaction (cfg.ordering == 2; LDS geometry, G <= 32)
-    bool use_bvh = false;            // candidate-list kernel (cfg.bvh 1 = BVH walk, 2 = uniform scan; <= 256 primitives)
-    BvhNode *d_nodes = nullptr; BoundRec *d_bounds = nullptr; unsigned char *d_order = nullptr;
-    int nnodes = 0;
     uint32_t nseg = 0, seg_slots = 0;     // level 0 (what k_generate fills)
     uint32_t lvl_slots[66] = {0}, lvl_nseg[66] = {0};   // level entering bounce b
     uint32_t *d_segcnt[2] = {nullptr, nullptr};
@@ -2061,10 +1442,6 @@ void free_scene_buffers(pt_context *c) {
     c->d_cull = nullptr;
     for (void *b : c->d_mesh_blobs) (void)hipFree(b);
     c->d_mesh_blobs.clear();
-    if (c->d_nodes) (void)hipFree(c->d_nodes);
-    if (c->d_bounds) (void)hipFree(c->d_bounds);
-    if (c->d_order) (void)hipFree(c->d_order);
-    c->d_nodes = nullptr; c->d_bounds = nullptr; c->d_order = nullptr;
     if (c->image == c->image_own) c->image = nullptr;
     c->image_own = nullptr; c->d_geoms = nullptr; c->d_mats = nullptr; c->d_status = nullptr; c->d_display = nullptr;
     c->scene_ready = false;
@@ -2126,43 +1503,6 @@ void world_bounds(const pt_geom &src, GeomRec *dst) {
     // the sphere test reports the point 1e-4 (object space, along the ray) in front of the surface
     dst->slack = src.type == 0 ? (float)(1.5e-4 * maxrow + 1e-5) : 1e-5f;
 }
-
-// median-split BVH over the primitives' conservative bounds (<= 4 per leaf)
-struct BvhBuild {
-    std::vector<BvhNode> nodes;
-    std::vector<unsigned char> order;
-    std::vector<float> lo, hi;       // 3 floats per primitive
-    int build(int first, int count) {
-        const int id = (int)nodes.size();
-        nodes.emplace_back();
-        float bmin[3] = {3e38f, 3e38f, 3e38f}, bmax[3] = {-3e38f, -3e38f, -3e38f};
-        for (int i = first; i < first + count; ++i)
-            for (int k = 0; k < 3; ++k) {
-                bmin[k] = std::fmin(bmin[k], lo[3 * order[i] + k]);
-                bmax[k] = std::fmax(bmax[k], hi[3 * order[i] + k]);
-            }
-        for (int k = 0; k < 3; ++k) { nodes[id].bmin[k] = bmin[k]; nodes[id].bmax[k] = bmax[k]; }
-        if (count <= 4) { nodes[id].a = ~first; nodes[id].b = count; return id; }
-        int axis = 0;
-        float ext = -1.0f;
-        for (int k = 0; k < 3; ++k) {            // split the axis with the widest spread of centres
-            float cmin = 3e38f, cmax = -3e38f;
-            for (int i = first; i < first + count; ++i) {
-                const float cc = 0.5f * (lo[3 * order[i] + k] + hi[3 * order[i] + k]);
-                cmin = std::fmin(cmin, cc); cmax = std::fmax(cmax, cc);
-            }
-            if (cmax - cmin > ext) { ext = cmax - cmin; axis = k; }
-        }
-        std::sort(order.begin() + first, order.begin() + first + count, [&](unsigned char x, unsigned char y) {
-            return lo[3 * x + axis] + hi[3 * x + axis] < lo[3 * y + axis] + hi[3 * y + axis];
-        });
-        const int half = count / 2;
-        const int l = build(first, half);
-        const int r = build(first + half, count - half);
-        nodes[id].a = l; nodes[id].b = r;
-        return id;
-    }
-};
 
 // ---- MESH: threaded BVH over the triangles of one mesh (object space), built at upload ----------------------
 // Median split of the triangle centroids along the widest axis, <= 4 triangles per leaf, nodes in depth-first
@@ -2265,17 +1605,6 @@ void mesh_world_bounds(const pt_geom &src, const pt_context::HostMesh &hm, GeomR
     dst->slack = (float)(1.5e-4 * maxrow + 1e-5);        // the hit point sits 1e-4 (object space) in front of the surface
 }
 
-template <bool LAST, bool GEN>
-int launch_bvh_t(pt_context *c, const SegArgs &a) {
-    BvhArgs bv;
-    bv.nodes = c->d_nodes; bv.nnodes = c->nnodes; bv.bounds = c->d_bounds; bv.order = c->d_order;
-    bv.walk = c->cfg.bvh == 1 ? 1 : 0;
-    hipLaunchKernelGGL((k_bounce_bvh<LAST, GEN>), dim3(c->grid_bounce), dim3(kBlock), c->lds_bytes, c->stream, a, bv,
-                       (const GeomRec *)c->d_geoms, (const MatRec *)c->d_mats);
-    HIPCHK(hipGetLastError());
-    return PT_OK;
-}
-
 template <bool LDS, bool LAST>
 int launch_bounce_t(pt_context *c, const BounceArgs &a) {
     hipLaunchKernelGGL((k_bounce<LDS, LAST>), dim3(c->grid_bounce), dim3(kBlock), c->lds_bytes, c->stream, a,
@@ -2321,22 +1650,6 @@ int launch_nee_t(pt_context *c, const SegArgs &a) {
 }
 
 template <bool LAST, bool GEN>
-int launch_bin_t(pt_context *c, const SegArgs &a) {
-    hipLaunchKernelGGL((k_bounce_bin<LAST, GEN>), dim3(c->grid_bounce), dim3(kBlock), c->lds_bytes, c->stream, a,
-                       (const GeomRec *)c->d_geoms, (const MatRec *)c->d_mats);
-    HIPCHK(hipGetLastError());
-    return PT_OK;
-}
-
-template <bool LAST, bool GEN>
-int launch_defer_t(pt_context *c, const SegArgs &a) {
-    hipLaunchKernelGGL((k_bounce_defer<LAST, GEN>), dim3(c->grid_bounce), dim3(kBlock), c->lds_bytes, c->stream, a,
-                       (const GeomRec *)c->d_geoms, (const MatRec *)c->d_mats);
-    HIPCHK(hipGetLastError());
-    return PT_OK;
-}
-
-template <bool LAST, bool GEN>
 int launch_q_t(pt_context *c, const SegArgs &a) {
     QTables qt;
     qt.frames = c->d_frames; qt.cull = c->d_cull; qt.nbox = c->q_nbox; qt.nsph = c->q_nsph;
@@ -2356,18 +1669,6 @@ int launch_seg(pt_context *c, const SegArgs &a, bool last, bool gen) {
         if (gen) return last ? launch_nee_t<true, true>(c, a) : launch_nee_t<false, true>(c, a);
         return last ? launch_nee_t<true, false>(c, a) : launch_nee_t<false, false>(c, a);
     }
-    if (c->use_bvh) {
-        if (gen) return last ? launch_bvh_t<true, true>(c, a) : launch_bvh_t<false, true>(c, a);
-        return last ? launch_bvh_t<true, false>(c, a) : launch_bvh_t<false, false>(c, a);
-    }
-    if (c->binned) {
-        if (gen) return last ? launch_bin_t<true, true>(c, a) : launch_bin_t<false, true>(c, a);
-        return last ? launch_bin_t<true, false>(c, a) : launch_bin_t<false, false>(c, a);
-    }
-    if (c->defer) {
-        if (gen) return last ? launch_defer_t<true, true>(c, a) : launch_defer_t<false, true>(c, a);
-        return last ? launch_defer_t<true, false>(c, a) : launch_defer_t<false, false>(c, a);
-    }
     if (c->wide) {
         if (gen) return last ? launch_wide_t<true, true>(c, a) : launch_wide_t<false, true>(c, a);
         return last ? launch_wide_t<true, false>(c, a) : launch_wide_t<false, false>(c, a);
@@ -2383,7 +1684,7 @@ int launch_seg(pt_context *c, const SegArgs &a, bool last, bool gen) {
 uint32_t seg_slots_for(const pt_context *c, uint32_t n_rays) {
     if (c->cfg.chunk_rays > 0) return c->seg_slots;
     // the sparse-work queue drains once per segment (one partly filled group): longer segments there
-    const bool longseg = c->defer || c->binned || c->queue;
+    const bool longseg = c->queue;
     const uint32_t slots = (uint32_t)c->grid_bounce * kWaves * (longseg ? 2u : 4u);
     uint32_t S = (((n_rays + slots - 1) / slots) + 63u) & ~63u;
     if (S < 192u) S = 192u;
@@ -2397,7 +1698,7 @@ void plan_levels(const pt_context *c, uint32_t n_rays, uint32_t *slots, uint32_t
     const uint32_t floor_segs = (uint32_t)(c->cfg.merge_floor > 0 ? c->cfg.merge_floor : 0);
     for (int b = 0; b < c->cfg.max_depth; ++b) {
         const uint32_t half = (nseg[b] + 1u) / 2u;
-        const bool merge = c->cfg.merge_floor > 0 && !c->binned && half >= floor_segs && slots[b] * 2u <= 65536u;
+        const bool merge = c->cfg.merge_floor > 0 && half >= floor_segs && slots[b] * 2u <= 65536u;
         slots[b + 1] = merge ? slots[b] * 2u : slots[b];
         nseg[b + 1] = merge ? half : nseg[b];
     }
@@ -2436,7 +1737,6 @@ int enqueue_iterations(pt_context *c, uint32_t iteration, uint32_t batch, int st
         a.bounce = b; a.iteration = iteration; a.n_own = c->n_own; a.cam = c->cam; a.bank = c->bank;
         a.pix_mask = c->pix_mask;
         a.n_rays = n_rays; a.batch = batch; a.planes = c->d_planes; a.plane_stride = (size_t)c->W * c->H * 3;
-        a.bin1_offset = c->nseg + 2u;
         a.lights = c->d_lights; a.nlights = c->nlights;
         a.nbc = c->nbc; a.nsc = c->nsc; a.cluster_bytes = c->wide ? c->cluster_bytes : 0u;
         const bool last = (stop_after < 0) && (b == D - 1);
@@ -2611,7 +1911,6 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     if (W < 2 || H < 2 || (int64_t)W * H > (1ll << 28)) { pth::set_error("pt_upload_scene: resolution %dx%d unsupported (2x2 .. 2^28 pixels)", W, H); return PT_ERR_ARGUMENT; }
     const bool big_frame = (int64_t)W * H > (1ll << 24);
     if (big_frame && c->cfg.direct_light != 0 && c->cfg.mode == 0) { pth::set_error("pt_upload_scene: direct_light supports frames up to 2^24 pixels (%dx%d asked)", W, H); return PT_ERR_ARGUMENT; }
-    if (big_frame && c->cfg.compaction == 0 && c->cfg.ordering == 2) { pth::set_error("pt_upload_scene: ordering=2 supports frames up to 2^24 pixels"); return PT_ERR_ARGUMENT; }
     std::vector<GeomRec> g(G);
     std::vector<MatRec> m(M);
     for (int i = 0; i < M; ++i) {
@@ -2662,15 +1961,11 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     }
     c->seg_mode = (c->cfg.compaction == 0);
     c->cull = (c->cfg.culling == 0) && c->seg_mode;
-    c->defer = c->cull && c->cfg.ordering == 3 && c->cfg.geometry_path == 0 && G <= 32 && c->cfg.mode == 0;
     c->queue = c->cull && c->cfg.ordering == 1 && c->cfg.geometry_path == 0 && G <= 32 && c->cfg.mode == 0 && c->cfg.merge_floor <= 0;
-    c->use_bvh = c->cull && c->cfg.mode == 0 && G <= 256 && (c->cfg.bvh == 1 || c->cfg.bvh == 2);   // opt-in: measured slower than block-wise culling
-    c->binned = c->cull && c->cfg.ordering == 2 && c->cfg.geometry_path == 0 && G <= 32 && c->cfg.mode == 0;
-    if (c->use_bvh) { c->defer = false; c->binned = false; c->queue = false; }
     c->geom_lds = (c->cfg.geometry_path == 0);
     if (have_mesh) {
         // meshes are traversed by the stable kernels only
-        c->defer = false; c->queue = false; c->binned = false; c->use_bvh = false;
+        c->queue = false;
         for (int i = 0; i < G; ++i) {
             if (!mesh_of[i]) continue;
             uint32_t tri_offset = 0;
@@ -2694,7 +1989,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
             pth::set_error("pt_upload_scene: direct_light needs compaction=0, culling=0, geometry_path=0");
             return PT_ERR_ARGUMENT;
         }
-        c->defer = false; c->binned = false; c->use_bvh = false; c->queue = false;
+        c->queue = false;
         std::vector<uint32_t> lights;
         for (int i = 0; i < G; ++i)
             if (mats[geoms[i].materialid].emittance > 0.0f) lights.push_back((uint32_t)i);
@@ -2704,46 +1999,18 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         HIPCHK(hipMemcpy(c->d_lights, lights.data(), lights.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
 
-    if (c->use_bvh) {
-        BvhBuild bb;
-        bb.order.resize(G); bb.lo.resize(3 * G); bb.hi.resize(3 * G);
-        std::vector<BoundRec> br(G);
-        for (int i = 0; i < G; ++i) {
-            bb.order[i] = (unsigned char)i;
-            memcpy(br[i].bmin, g[i].bmin, 16); memcpy(br[i].bmax, g[i].bmax, 16);
-            br[i].type = g[i].type; br[i].slack = g[i].slack; br[i].pad[0] = br[i].pad[1] = 0;
-            for (int k = 0; k < 3; ++k) {
-                if (g[i].type == 0) { bb.lo[3 * i + k] = g[i].bmin[k] - g[i].bmax[3]; bb.hi[3 * i + k] = g[i].bmin[k] + g[i].bmax[3]; }
-                else if (g[i].type == 1) { bb.lo[3 * i + k] = g[i].bmin[k]; bb.hi[3 * i + k] = g[i].bmax[k]; }
-                else { bb.lo[3 * i + k] = 0.0f; bb.hi[3 * i + k] = 0.0f; }      // MESH: never a candidate (type check in the leaf)
-            }
-        }
-        bb.build(0, G);
-        c->nnodes = (int)bb.nodes.size();
-        if (c->nnodes > 255) { c->use_bvh = false; }                 // stack entries are one byte
-        else {
-            HIPCHK(hipMalloc(&c->d_nodes, bb.nodes.size() * sizeof(BvhNode)));
-            HIPCHK(hipMalloc(&c->d_bounds, (size_t)G * sizeof(BoundRec)));
-            HIPCHK(hipMalloc(&c->d_order, (size_t)G));
-            HIPCHK(hipMemcpy(c->d_nodes, bb.nodes.data(), bb.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(c->d_bounds, br.data(), (size_t)G * sizeof(BoundRec), hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(c->d_order, bb.order.data(), (size_t)G, hipMemcpyHostToDevice));
-        }
-    }
-
     // LDS budget: tables (+ the ray stage of the look-back variant)
     uint32_t tb = tables_bytes(G, M, c->geom_lds);
-    const uint32_t stage_bytes = c->seg_mode ? (c->defer ? kWaves * kQueueCap * kQueueFields * (uint32_t)sizeof(float)
-                                                : c->queue ? q_lds_offset(G, M) - tables_bytes(G, M, true) + kWaves * kQCap * kQFields * (uint32_t)sizeof(float) : 0u)
+    const uint32_t stage_bytes = c->seg_mode ? (c->queue ? q_lds_offset(G, M) - tables_bytes(G, M, true) + kWaves * kQCap * kQFields * (uint32_t)sizeof(float) : 0u)
                                              : kBlock * c->rpt * kFields * (uint32_t)sizeof(float);
     if (c->geom_lds && tb + stage_bytes > 160u * 1024u) {   // table too large for LDS: scalar-load path
         if (c->nee) { pth::set_error("pt_upload_scene: direct_light needs the geometry table in LDS (%d primitives do not fit)", G); return PT_ERR_ARGUMENT; }
         c->geom_lds = false;
         tb = tables_bytes(G, M, false);
     }
-    c->lds_bytes = c->use_bvh ? bvh_lds_bytes(G, M, c->nnodes) : tb + stage_bytes;
+    c->lds_bytes = tb + stage_bytes;
     // 33..256 primitives with the table in LDS: the mask-register / packed-list variant (PT_WIDE=0 turns it off)
-    c->wide = c->cull && c->geom_lds && !c->nee && !c->use_bvh && !c->defer && !c->binned && !c->queue && !have_mesh && c->cfg.mode == 0 && G > 32 && G <= 256;
+    c->wide = c->cull && c->geom_lds && !c->nee && !c->queue && !have_mesh && c->cfg.mode == 0 && G > 32 && G <= 256;
     if (const char *wv = getenv("PT_WIDE")) if (atoi(wv) == 0) c->wide = false;
     // two-level culling of the many-primitive variant: clusters of <= kClusterSize primitives of one type
     std::vector<unsigned char> cluster_blob;
@@ -2845,10 +2112,8 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         int occ = 0;
         const void *fn = c->wide ? reinterpret_cast<const void *>(&k_bounce_seg<true, false, true, false, false, true>)
                        : c->nee ? nee_fns[0]
-                       : c->binned ? reinterpret_cast<const void *>(&k_bounce_bin<false, false>)
-                       : c->use_bvh ? reinterpret_cast<const void *>(&k_bounce_bvh<false, false>)
                        : c->queue ? reinterpret_cast<const void *>(&k_bounce_q<false, false>)
-                       : c->defer ? reinterpret_cast<const void *>(&k_bounce_defer<false, false>) : fns[(c->seg_mode ? 4 : 0) + (c->geom_lds ? 0 : 1)];
+                       : fns[(c->seg_mode ? 4 : 0) + (c->geom_lds ? 0 : 1)];
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, kBlock, c->lds_bytes) != hipSuccess || occ < 1) occ = 2;
         per_cu = occ;
     }
@@ -2894,8 +2159,8 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         c->grid_bounce = grid;
         plan_levels(c, max_rays, c->lvl_slots, c->lvl_nseg);
         for (int i = 0; i < 2; ++i) {
-            HIPCHK(hipMalloc(&c->d_segcnt[i], (size_t)(c->nseg + 2u) * 2 * sizeof(uint32_t)));     // [bin 0 | bin 1]
-            HIPCHK(hipMemsetAsync(c->d_segcnt[i], 0, (size_t)(c->nseg + 2u) * 2 * sizeof(uint32_t), c->stream));
+            HIPCHK(hipMalloc(&c->d_segcnt[i], (size_t)(c->nseg + 2u) * sizeof(uint32_t)));
+            HIPCHK(hipMemsetAsync(c->d_segcnt[i], 0, (size_t)(c->nseg + 2u) * sizeof(uint32_t), c->stream));
         }
         c->status_words = 0;
     } else {
@@ -2910,7 +2175,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     if (grid < 1) grid = 1;
     c->grid_bounce = grid;
 
-    for (int i = 0; i < 2; ++i) HIPCHK(hipMalloc(&c->pool[i], (size_t)c->cap * kPoolFields * sizeof(float)));
+    for (int i = 0; i < 2; ++i) HIPCHK(hipMalloc(&c->pool[i], (size_t)c->cap * kFields * sizeof(float)));
     HIPCHK(hipMalloc(&c->image_own, (size_t)W * H * 3 * sizeof(float)));
     HIPCHK(hipMemsetAsync(c->image_own, 0, (size_t)W * H * 3 * sizeof(float), c->stream));
     if (!c->image) c->image = c->image_own;
@@ -3247,11 +2512,8 @@ int pt_debug_trace_pool(pt_context *c, int iteration, int bounces, int *count, f
         std::vector<uint32_t> cnt(nseg);
         HIPCHK(hipMemcpy(cnt.data(), c->d_segcnt[bounces & 1], (size_t)nseg * 4, hipMemcpyDeviceToHost));
         std::vector<float> field(c->cap);
-        std::vector<uint32_t> cnt1(nseg, 0u);
-        if (c->binned && bounces > 0)
-            HIPCHK(hipMemcpy(cnt1.data(), c->d_segcnt[bounces & 1] + c->nseg + 2u, (size_t)nseg * 4, hipMemcpyDeviceToHost));
         uint64_t total = 0;
-        for (uint32_t sgi = 0; sgi < nseg; ++sgi) total += cnt[sgi] + cnt1[sgi];
+        for (uint32_t sgi = 0; sgi < nseg; ++sgi) total += cnt[sgi];
         if (total != n) { pth::set_error("segment counts (%llu) disagree with the live counter (%u)", (unsigned long long)total, n); return PT_ERR_HIP; }
         for (int f = 0; f < 10; ++f) {
             float *out = f < 9 ? dst[f] : reinterpret_cast<float *>(pixel);
@@ -3261,8 +2523,6 @@ int pt_debug_trace_pool(pt_context *c, int iteration, int bounces, int *count, f
             for (uint32_t sgi = 0; sgi < nseg; ++sgi) {
                 memcpy(out + w, field.data() + (size_t)sgi * slots, (size_t)cnt[sgi] * 4);
                 w += cnt[sgi];
-                if (c->binned && bounces > 0)                         // back run of the two-ended segment
-                    for (uint32_t q = 0; q < cnt1[sgi]; ++q) out[w++] = field[(size_t)sgi * slots + slots - 1u - q];
             }
         }
     }

@@ -161,7 +161,7 @@ def test_image_and_live_counts_match_oracle(pt, scene_name, depth, iters):
     assert not np.isnan(img).any()
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(ordering=1), dict(ordering=2), dict(direct_light=1)])
+@pytest.mark.parametrize("kw", [dict(), dict(ordering=1), dict(direct_light=1)])
 def test_long_launch_groups_use_every_slot_bit(pt, kw):
     """Small frames batch up to 128 iterations into one launch group (slot = bits 24..30 of the pixel
     word, bit 31 = the direct-light flag): 150 iterations = one full group + a partial one."""
@@ -190,7 +190,7 @@ def test_accumulation_continues_from_host_image(pt, cornell200):
 
 
 @pytest.mark.parametrize("kw", [dict(geometry_path=1), dict(chunk_rays=64), dict(batch=1), dict(batch=2), dict(batch=3, chunk_rays=100), dict(chunk_rays=64, merge_floor=3000), dict(chunk_rays=64, merge_floor=50, batch=2), dict(chunk_rays=1000), dict(chunk_rays=16, merge_floor=1), dict(chunk_rays=100, merge_floor=7), dict(blocks_per_cu=1),
-                                dict(culling=1), dict(culling=1, geometry_path=1), dict(bvh=1), dict(bvh=1, batch=3, chunk_rays=64), dict(ordering=2), dict(ordering=2, batch=2, chunk_rays=100), dict(ordering=2, batch=1), dict(ordering=1), dict(ordering=1, batch=2), dict(ordering=1, chunk_rays=100, merge_floor=7), dict(ordering=1, batch=1, chunk_rays=64), dict(ordering=1, chunk_rays=128, blocks_per_cu=1), dict(ordering=3), dict(ordering=3, batch=2, chunk_rays=100),
+                                dict(culling=1), dict(culling=1, geometry_path=1), dict(ordering=1), dict(ordering=1, batch=2), dict(ordering=1, chunk_rays=100, merge_floor=7), dict(ordering=1, batch=1, chunk_rays=64), dict(ordering=1, chunk_rays=128, blocks_per_cu=1), dict(ordering=1, batch=5, blocks_per_cu=2),
                                 dict(compaction=1), dict(compaction=1, chunk_rays=256), dict(compaction=1, chunk_rays=1024, geometry_path=1)])
 def test_launch_variants_are_bit_identical(pt, cornell200, kw):
     ref = make_tracer(cornell200)
@@ -370,20 +370,22 @@ def test_full_size_properties_1080p(pt):
     assert np.array_equal(got[rows], a[rows])
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(bvh=1), dict(bvh=2), dict(geometry_path=1), dict(culling=1), dict(bvh=1, batch=2, chunk_rays=100)])
+@pytest.mark.parametrize("kw", [dict(), dict(batch=2, chunk_rays=100), dict(geometry_path=1), dict(culling=1), dict(streams=2), dict(direct_light=1)])
 def test_many_primitives_scene_matches_oracle(pt, kw):
-    """BASELINE config 4's scene (256 spheres+cubes incl. rotated cubes, mirrors, glass): the
+    """BASELINE config 4's scene (256 spheres+cubes incl. rotated cubes, mirrors, glass): the two-level
     candidate culling must never change the nearest hit."""
     sc = orc.load_golden_scene("random256").with_resolution(192, 108)
     tr = make_tracer(sc, depth=8, **kw)
     tr.set_image(None); tr.render(1, 2)
-    want, live = orc.render(sc, oracle_config(8), 1, 2)
+    okw = {k: v for k, v in kw.items() if k == "direct_light"}
+    want, live = orc.render(sc, oracle_config(8, **okw), 1, 2)
     st = tr.stats()
     assert [st.live[k] for k in range(9)] == [int(v) for v in live]
     assert np.array_equal(tr.image(), want)
-    n, arrs, pix = tr.trace_pool(2, 3)
-    on, oarrs, opix = orc.trace_pool(sc, oracle_config(8), 2, 3)
-    assert n == on and np.array_equal(pix, opix) and all(np.array_equal(a, b) for a, b in zip(arrs, oarrs))
+    if kw.get("streams", 1) == 1:
+        n, arrs, pix = tr.trace_pool(2, 3)
+        on, oarrs, opix = orc.trace_pool(sc, oracle_config(8, **okw), 2, 3)
+        assert n == on and np.array_equal(pix, opix) and all(np.array_equal(a, b) for a, b in zip(arrs, oarrs))
 
 
 def test_stats_survive_the_parity_hook_and_repeated_iterations(pt, cornell200):
@@ -508,10 +510,10 @@ def test_light_sampling_helpers_bit_exact(pt):
 @pytest.mark.parametrize("scene_name,depth,iters,kw", [
     ("sampleScene", 8, 5, dict()), ("cornell_mirror", 8, 4, dict()), ("cornell_glass_4k", 12, 3, dict()),
     ("cornell_glass_4k", 6, 3, dict(camera_mode=1, antialias=1, aperture=0.25, focal_distance=12.0))])
-@pytest.mark.parametrize("ordering", [1, 2, 3])
+@pytest.mark.parametrize("ordering", [1])
 def test_sparse_work_queue_ordering_is_bit_identical(pt, scene_name, depth, iters, kw, ordering):
-    """ordering=1 (typed work queues: one exact test per stage on full waves), 2 (binned) and 3 (round 1's ring of
-    complex rays): same image, same live counts as the oracle; the pool holds the same set of rays."""
+    """ordering=1 (typed work queues: one exact test per stage on full waves): same image, same live counts as the
+    oracle; the pool holds the same set of rays."""
     sc = orc.load_golden_scene(scene_name).with_resolution(200, 150)
     tr = make_tracer(sc, depth=depth, ordering=ordering, **kw)
     tr.set_image(None); tr.render(1, iters)
