@@ -3,16 +3,16 @@
 // Replaces the body of cudaRaytraceCore (/root/reference/src/raytraceKernel.cu:164-227) and the
 // kernels it launches (raytraceRay :123-159, sendImageToPBO :88-119) with a wavefront design:
 //
-//   k_generate   camera rays -> SoA ray pool (40 B/ray), resets the per-iteration sync block
-//   k_bounce     persistent blocks pull 256*RPT-ray chunks by ticket; each wave traces its
-//                contiguous span against the LDS-staged (or scalar-loaded) geometry table,
-//                scatters, accumulates emitter hits into the image, compacts survivors into a
-//                wave-private LDS stage (ballot + mbcnt), and the block places them in the
-//                output pool through a decoupled look-back scan over 8-byte {state,value}
-//                granules -> STABLE (generation-order) compaction in one pass
-//   k_bounce_last  final bounce: emitters only, nothing written back
-//   k_flat       the reference kernel as shipped (one hit, flat colour overwrite)
-//   k_display    sendImageToPBO
+//   k_bounce_seg   (default) one wave streams its pool segments 64 rays at a time: [bounce 0: camera ray] ->
+//                  conservative candidate culling -> exact reference tests -> scatter -> accumulate ->
+//                  ballot/mbcnt compaction straight into the output segment (stable order).  Variants:
+//                  NEE (direct light), WIDE (33..256 primitives: two-level cluster culling), meshes.
+//   k_bounce_q     (ordering = 1, <= 32 primitives) the same work as two wave-private stages with LDS work
+//                  queues by candidate type: every exact test and every shading runs on a full wave
+//   k_generate + k_bounce   (compaction = 1) separate generation, dense pool, decoupled look-back scan
+//   k_fold         adds the per-iteration accumulator planes of a launch group to the image in iteration order
+//   k_flat         the reference kernel as shipped (one hit, flat colour overwrite) + primary-hit parity hook
+//   k_display      sendImageToPBO
 //
 // No CPU fallback lives here: every entry point needs a gfx950 device.
 #include <hip/hip_runtime.h>
