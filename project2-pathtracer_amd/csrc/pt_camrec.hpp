@@ -12,6 +12,9 @@ struct CamRec {
     int W, Hh;
     int camera_mode, antialias;
     int row_offset, row_stride;
+    // exact division of a pixel index (< 2^28) by W and of a row number by row_stride as multiply + shift
+    // (q = (n * m) >> sh, m = floor(2^sh / d) + 1, sh = 28 + ceil(log2 d)): global pixel -> index among the owned pixels
+    unsigned int mW, shW, mS, shS;
 };
 
 }  // namespace ptd

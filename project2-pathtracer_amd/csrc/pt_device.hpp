@@ -507,6 +507,15 @@ PTD_FN int scatter_box(const MatRec &m, f3 P, int face, const FaceFrame *frames,
     return code;
 }
 
+// global pixel index (x + y*W, y owned by this context) -> index among the context's owned pixels (local row * W + x):
+// the per-iteration accumulator planes of a launch group hold only the owned rows
+PTD_FN uint32_t owned_index(const CamRec &c, uint32_t pixel) {
+    const uint32_t y = (uint32_t)(((unsigned long long)pixel * c.mW) >> c.shW);
+    const uint32_t x = pixel - y * (uint32_t)c.W;
+    const uint32_t ly = (uint32_t)(((unsigned long long)(y - (uint32_t)c.row_offset) * c.mS) >> c.shS);
+    return ly * (uint32_t)c.W + x;
+}
+
 // ---------------------------------------------------------------- camera ---------------
 // per-pixel half of raycastFromCameraKernel (src/raytraceKernel.cu:62-74)
 PTD_FN void camera_ray(const CamRec &c, uint32_t pixel, uint32_t iteration, f3 &o, f3 &d) {

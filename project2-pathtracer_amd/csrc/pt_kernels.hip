@@ -446,9 +446,10 @@ __global__ __launch_bounds__(kBlock) void k_generate(GenArgs a) {
 // are updated in place.  LAST: depth exhausted -- only emitters matter, survivors are counted.
 // material -> scatter / emit for a ray whose nearest hit is known.  Returns true while the path stays
 // alive; o, d, thr are updated in place.  LAST: depth exhausted -- only emitters matter.
+// `acc` is the frame (index = global pixel) or, with `cam` given, an accumulator plane of the owned rows only.
 template <bool LAST>
 __device__ __forceinline__ bool shade_hit(const MatRec m, f3 P, f3 N, int bounce, uint32_t iteration, float *image,
-                                          uint32_t pixel, f3 &o, f3 &d, f3 &thr, uint32_t &emitted) {
+                                          uint32_t pixel, f3 &o, f3 &d, f3 &thr, uint32_t &emitted, const CamRec *plane_cam = nullptr) {
     if (LAST && !(m.emittance > 0.0f)) return true;       // depth exhausted: alive, contributes 0
     uint32_t st = lcg_seed(stream_seed(pixel, iteration, 1u + (uint32_t)bounce));
     st = lcg_next(st); const float u_sel = u01(st);
@@ -458,7 +459,7 @@ __device__ __forceinline__ bool shade_hit(const MatRec m, f3 P, f3 N, int bounce
     const int code = scatter(m, P, N, u_sel, xi1, xi2, o, d, thr, L);
     if (code == 3) {
         // exactly one live path per pixel per iteration (slot): plain read-modify-write, no atomics
-        float *px = image + (size_t)pixel * 3;
+        float *px = image + (size_t)(plane_cam ? owned_index(*plane_cam, pixel) : pixel) * 3;
         px[0] = px[0] + L.x; px[1] = px[1] + L.y; px[2] = px[2] + L.z;
         emitted++;
     }
@@ -468,7 +469,7 @@ __device__ __forceinline__ bool shade_hit(const MatRec m, f3 P, f3 N, int bounce
 template <bool GEOM_LDS, bool LAST, bool CULL, bool WIDE = false>
 __device__ __forceinline__ bool bounce_ray(const GeomRec *lg, const GeomRec *__restrict__ geoms, const MatRec *lm,
                                            int G, int bounce, uint32_t iteration, float *image, uint32_t pixel,
-                                           f3 &o, f3 &d, f3 &thr, uint32_t &emitted, int nbc = 0, int nsc = 0) {
+                                           f3 &o, f3 &d, f3 &thr, uint32_t &emitted, int nbc = 0, int nsc = 0, const CamRec *plane_cam = nullptr) {
     float t;
     f3 P, N;
     int hit;
@@ -478,7 +479,7 @@ __device__ __forceinline__ bool bounce_ray(const GeomRec *lg, const GeomRec *__r
     else hit = nearest_hit(geoms, G, o, d, t, P, N);
     if (hit < 0) return false;
     const int mid = GEOM_LDS ? lg[hit].mat : geoms[hit].mat;
-    return shade_hit<LAST>(lm[mid], P, N, bounce, iteration, image, pixel, o, d, thr, emitted);
+    return shade_hit<LAST>(lm[mid], P, N, bounce, iteration, image, pixel, o, d, thr, emitted, plane_cam);
 }
 
 // direct_light variant (k_bounce_seg only; LDS tables, culling on).  At a diffuse
@@ -488,7 +489,7 @@ __device__ __forceinline__ bool bounce_ray(const GeomRec *lg, const GeomRec *__r
 template <bool LAST>
 __device__ __forceinline__ bool bounce_ray_nee(const GeomRec *lg, const GeomRec *__restrict__ geoms, const MatRec *lm, int G,
                                                const uint32_t *__restrict__ lights, uint32_t nlights, int bounce,
-                                               uint32_t iteration, float *acc, uint32_t pixel, f3 &o, f3 &d, f3 &thr,
+                                               uint32_t iteration, float *acc, uint32_t acc_index, uint32_t pixel, f3 &o, f3 &d, f3 &thr,
                                                uint32_t &emitted, uint32_t &flag) {
     float t;
     f3 P, N;
@@ -503,7 +504,7 @@ __device__ __forceinline__ bool bounce_ray_nee(const GeomRec *lg, const GeomRec 
     const f3 d_in = d;
     f3 L = mk(0.0f, 0.0f, 0.0f);
     const int code = scatter(m, P, N, u_sel, xi1, xi2, o, d, thr, L);
-    float *px = acc + (size_t)pixel * 3;
+    float *px = acc + (size_t)acc_index * 3;
     if (code == 3) {
         if (flag) { px[0] = px[0] + L.x; px[1] = px[1] + L.y; px[2] = px[2] + L.z; }
         emitted++;
@@ -777,12 +778,13 @@ __global__ __launch_bounds__(kBlock, (NEE || WIDE) ? 4 : PT_SEG_WAVES) void k_bo
                 if (NEE) {
                     // every contribution of a path goes to its iteration's plane (folded afterwards)
                     float *acc = a.planes + (size_t)slot * a.plane_stride;
-                    alive = bounce_ray_nee<LAST>(lg, geoms, lm, a.G, a.lights, a.nlights, a.bounce, a.iteration + slot, acc, pixel,
+                    alive = bounce_ray_nee<LAST>(lg, geoms, lm, a.G, a.lights, a.nlights, a.bounce, a.iteration + slot, acc, owned_index(a.cam, pixel), pixel,
                                                  o, d, thr, emitted, flag);
                     pixel |= (slot << 24) | (flag << 31);
                 } else {
                     float *acc = a.batch > 1u ? a.planes + (size_t)slot * a.plane_stride : a.image;
-                    alive = bounce_ray<GEOM_LDS, LAST, CULL, WIDE>(lg, geoms, lm, a.G, a.bounce, a.iteration + slot, acc, pixel, o, d, thr, emitted, a.nbc, a.nsc);
+                    alive = bounce_ray<GEOM_LDS, LAST, CULL, WIDE>(lg, geoms, lm, a.G, a.bounce, a.iteration + slot, acc, pixel, o, d, thr, emitted, a.nbc, a.nsc,
+                                                                   a.batch > 1u ? &a.cam : nullptr);
                     pixel |= slot << 24;
                 }
             }
@@ -1142,8 +1144,8 @@ __global__ __launch_bounds__(kBlock, PT_Q_WAVES) void k_bounce_q(SegArgs a, cons
                 if (__any(hb)) { if (hb) code = scatter_box(m, P, face, lf + 3 * hit, u_sel, xi1, xi2, o, d, thr, L); }
                 if (__any(!hb)) { if (!hb) code = scatter(m, P, N, u_sel, xi1, xi2, o, d, thr, L); }
                 if (code == 3) {
-                    float *acc = a.batch > 1u ? a.planes + (size_t)slot * a.plane_stride : a.image;
-                    float *px = acc + (size_t)pixel * 3;
+                    float *px = a.batch > 1u ? a.planes + (size_t)slot * a.plane_stride + (size_t)owned_index(a.cam, pixel) * 3
+                                             : a.image + (size_t)pixel * 3;
                     (void)unsafeAtomicAdd(px, L.x); (void)unsafeAtomicAdd(px + 1, L.y); (void)unsafeAtomicAdd(px + 2, L.z);
                     emitted++;
                 }
@@ -1216,7 +1218,7 @@ __global__ __launch_bounds__(kBlock) void k_fold(FoldArgs a) {
     const size_t p = ((size_t)(lr * (uint32_t)a.row_stride + (uint32_t)a.row_offset) * W + x) * 3;
     float r = a.image[p], g = a.image[p + 1], b = a.image[p + 2];
     for (uint32_t s = 0; s < a.batch; ++s) {
-        float *q = a.planes + (size_t)s * a.plane_stride + p;
+        float *q = a.planes + (size_t)s * a.plane_stride + (size_t)gid * 3;       // planes hold the owned pixels only
         r = r + q[0]; g = g + q[1]; b = b + q[2];
         q[0] = 0.0f; q[1] = 0.0f; q[2] = 0.0f;
     }
@@ -1360,7 +1362,7 @@ struct pt_context {
     uint32_t batch_max = 1;          // iterations that may share one launch group
     uint32_t pix_mask = 0xFFFFFFu;   // pixel bits of the pool's pixel word (all 32 for frames above 2^24 pixels)
     bool empty = false;              // this context owns no row of the frame (row_offset >= H): every call is a no-op
-    float *d_planes = nullptr;       // batch_max accumulator planes (W*H*3 floats each)
+    float *d_planes = nullptr;       // batch_max accumulator planes (owned pixels x 3 floats each)
     bool wide = false;               // 33..256 primitives in LDS: k_bounce_seg<.., WIDE> (two-level cluster culling -> packed candidate lists)
     int nbc = 0, nsc = 0;            // its cube / sphere clusters, stored behind the GeomRec array of d_geoms
     uint32_t cluster_bytes = 0;
@@ -1736,7 +1738,7 @@ int enqueue_iterations(pt_context *c, uint32_t iteration, uint32_t batch, int st
         a.merge = c->lvl_slots[b + 1] != c->lvl_slots[b] ? 1u : 0u;
         a.bounce = b; a.iteration = iteration; a.n_own = c->n_own; a.cam = c->cam; a.bank = c->bank;
         a.pix_mask = c->pix_mask;
-        a.n_rays = n_rays; a.batch = batch; a.planes = c->d_planes; a.plane_stride = (size_t)c->W * c->H * 3;
+        a.n_rays = n_rays; a.batch = batch; a.planes = c->d_planes; a.plane_stride = (size_t)c->n_own * 3;
         a.lights = c->d_lights; a.nlights = c->nlights;
         a.nbc = c->nbc; a.nsc = c->nsc; a.cluster_bytes = c->wide ? c->cluster_bytes : 0u;
         const bool last = (stop_after < 0) && (b == D - 1);
@@ -1746,7 +1748,7 @@ int enqueue_iterations(pt_context *c, uint32_t iteration, uint32_t batch, int st
     if (c->seg_mode && (batch > 1u || c->nee)) {
         Scoped s(c, 0);
         FoldArgs f;
-        f.image = c->image; f.planes = c->d_planes; f.plane_stride = (size_t)c->W * c->H * 3;
+        f.image = c->image; f.planes = c->d_planes; f.plane_stride = (size_t)c->n_own * 3;
         f.batch = batch; f.n_own = c->n_own; f.W = c->W; f.row_offset = c->cfg.row_offset; f.row_stride = c->cfg.row_stride;
         hipLaunchKernelGGL(k_fold, dim3((c->n_own + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, f);
         HIPCHK(hipGetLastError());
@@ -2137,8 +2139,8 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         if (c->cfg.mode == 0 && !big_frame) {
             if (c->cfg.batch > 0) K = (uint32_t)c->cfg.batch;
             else K = (uint32_t)((32u * 1024u * 1024u) / n_own);      // 16 at 1080p: measured best (14: +4 %, 18: +8 % time)
-            // the slot field has 7 bits beside the count-emission flag; the planes are full frames: <= 4 GiB
-            const uint64_t plane_bytes = (uint64_t)W * H * 3 * sizeof(float);
+            // the slot field has 7 bits beside the count-emission flag; a plane holds the owned pixels: <= 4 GiB in all
+            const uint64_t plane_bytes = (uint64_t)n_own * 3 * sizeof(float);
             const uint32_t by_memory = (uint32_t)((4ull << 30) / plane_bytes);
             if (K > 128u) K = 128u;
             if (K > by_memory) K = by_memory;
@@ -2150,8 +2152,8 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         c->cap = max_rays + 2u * (c->cfg.merge_floor > 0 ? 65536u : 4096u);
         c->max_chunks = c->nseg;
         if (K > 1u || c->nee) {
-            HIPCHK(hipMalloc(&c->d_planes, (size_t)K * W * H * 3 * sizeof(float)));
-            HIPCHK(hipMemsetAsync(c->d_planes, 0, (size_t)K * W * H * 3 * sizeof(float), c->stream));
+            HIPCHK(hipMalloc(&c->d_planes, (size_t)K * n_own * 3 * sizeof(float)));
+            HIPCHK(hipMemsetAsync(c->d_planes, 0, (size_t)K * n_own * 3 * sizeof(float), c->stream));
         }
         const uint32_t blocks_needed = (c->nseg + kWaves - 1) / kWaves;
         if ((uint32_t)grid > blocks_needed) grid = (int)blocks_needed;

@@ -229,6 +229,14 @@ void camera_basis(const pt_camera *cam, const pt_config *cfg, ptd::CamRec *out) 
     out->antialias = cfg->antialias;
     out->row_offset = cfg->row_offset;
     out->row_stride = cfg->row_stride;
+    auto magic = [](unsigned int d, unsigned int *m, unsigned int *sh) {
+        unsigned int L = 0;
+        while ((1u << L) < d) ++L;
+        *sh = 28u + L;
+        *m = (unsigned int)(((1ull << *sh) / d) + 1ull);
+    };
+    magic((unsigned int)(out->W > 0 ? out->W : 1), &out->mW, &out->shW);
+    magic((unsigned int)(out->row_stride > 0 ? out->row_stride : 1), &out->mS, &out->shS);
 }
 
 }  // namespace pth

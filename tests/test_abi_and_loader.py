@@ -154,3 +154,24 @@ def test_tokenizer_cases_from_reference(pkg):
     T = json.load(open(os.path.join(orc.GOLD, "ref_tokens.json")))
     for case in T["cases"]:
         assert case["line"].split() == case["tokens"]
+
+
+def test_owned_index_magic_division_is_exact():
+    """csrc/pt_scene.cpp camera_basis / csrc/pt_device.hpp owned_index: q = (n * m) >> sh with m = floor(2^sh / d) + 1,
+    sh = 28 + ceil(log2 d) must equal n // d for every n < 2^28 (pixel indices) -- checked here on the formula itself
+    at the edges of every quotient step for a spread of divisors, plus random n."""
+    import random
+    rnd = random.Random(7)
+    for d in [1, 2, 3, 5, 7, 8, 64, 100, 640, 799, 800, 1000, 1920, 2048, 3840, 4095, 4096, 4100, 16384, 32767, 32768]:
+        L = 0
+        while (1 << L) < d:
+            L += 1
+        sh = 28 + L
+        m = (1 << sh) // d + 1
+        assert m < (1 << 32)
+        ns = [rnd.randrange(1 << 28) for _ in range(20000)] + [(1 << 28) - 1, 0]
+        for q in [rnd.randrange((1 << 28) // d) for _ in range(2000)] + [(1 << 28) // d - 1]:
+            ns += [q * d, q * d + d - 1, max(0, q * d - 1)]
+        for n in ns:
+            if n < (1 << 28):
+                assert (n * m) >> sh == n // d, (n, d)
