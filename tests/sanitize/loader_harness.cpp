@@ -36,6 +36,22 @@ int main(int argc, char **argv) {
             float T[16], Ti[16];
             for (int o = -1; o <= G; ++o) (void)pt_scene_object_matrices(s, o, f, T, Ti);
         }
+        // MESH objects: every accessor, in and out of range
+        const int nm = pt_scene_mesh_count(s);
+        for (int k = -1; k <= nm; ++k) {
+            pt_mesh me;
+            memset(&me, 0, sizeof me);
+            const int r = pt_scene_mesh(s, k, &me);
+            if ((k < 0 || k >= nm) ? r == PT_OK : r != PT_OK) { fprintf(stderr, "pt_scene_mesh(%d) of %s: rc=%d\n", k, argv[i], r); pt_scene_free(s); return 9; }
+            if (r == PT_OK) {
+                long long sum = 0;
+                for (int t = 0; t < 3 * me.ntriangles; ++t) {
+                    if (me.indices[t] < 0 || me.indices[t] >= me.nvertices) { fprintf(stderr, "index out of range in %s\n", argv[i]); pt_scene_free(s); return 10; }
+                    sum += (long long)me.vertices[3 * me.indices[t]];          // touches every referenced vertex
+                }
+                (void)sum;
+            }
+        }
         pt_scene_free(s);
         loaded++;
     }

@@ -86,6 +86,28 @@ int main(void) {
         float out[3];
         orc_rng_from_thread(800.0f, 800.0f, seeds[i] > 1e6f ? 3.0f : seeds[i], 17, 5, out);
     }
+    /* a MESH primitive (octahedron, 8 triangles) in place of the rotated glass cube: registry, brute-force test, render */
+    {
+        static const float ov[18] = {.5f, 0, 0, -.5f, 0, 0, 0, .5f, 0, 0, -.5f, 0, 0, 0, .5f, 0, 0, -.5f};
+        static const int oi[24] = {0, 2, 4, 2, 1, 4, 1, 3, 4, 3, 0, 4, 2, 0, 5, 1, 2, 5, 3, 1, 5, 0, 3, 5};
+        g[7].type = 2;
+        const int gi[1] = {7}, nv[1] = {6}, nt[1] = {8};
+        const float *vp[1] = {ov};
+        const int *ip[1] = {oi};
+        if (orc_set_meshes(gi, vp, nv, ip, nt, 1) != 0) return 5;
+        orc_config cfg;
+        memset(&cfg, 0, sizeof cfg);
+        cfg.max_depth = 6; cfg.row_stride = 1; cfg.direct_light = 1;
+        float *img2 = (float *)calloc((size_t)W * H * 3, sizeof(float));
+        if (orc_render(g, n, m, 6, &cam, &cfg, 1, 3, img2, live, 2) != 0) return 6;
+        for (int k = 0; k <= 6; k++) total += (double)live[k];
+        float P[3], N[3];
+        int tri = -1;
+        const float o[3] = {0, 1.5f, 12}, d[3] = {0, 0, -1};
+        total += orc_mesh_test(&g[7], ov, oi, 8, o, d, P, N, &tri) > 0 ? 1 : 0;
+        (void)orc_set_meshes(NULL, NULL, NULL, NULL, NULL, 0);
+        free(img2);
+    }
     free(hit); free(u8); free(img);
     printf("ok %.0f\n", total);
     return 0;

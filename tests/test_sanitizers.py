@@ -78,6 +78,47 @@ def test_damaged_scenes_never_crash_the_loader(harness, tmp_path):
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
 
 
+def test_damaged_obj_files_never_crash_the_loader(harness, tmp_path):
+    """The OBJ reader behind MESH objects: good meshes load, damaged ones (truncated, garbage, absurd or zero indices, no
+    faces, huge polygons) are refused with PT_ERR_PARSE -- never a crash or an out-of-range index handed to the caller."""
+    import shutil
+    scene = open(os.path.join(ROOT, "scenes", "cornell_mesh.txt")).read()
+    obj = open(os.path.join(ROOT, "scenes", "meshes", "torus.obj")).read()
+    olines = obj.split("\n")
+    rng = random.Random(99)
+    variants = [obj, "", "v 1 2\nf 1 1 1\n", "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2\n", "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 0 1 2\n",
+                "v 0 0 0\nv 1 0 0\nv 0 1 0\nf -4 1 2\n", "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 99999999999\n", "v nan inf -inf\nv 1 0 0\nv 0 1 0\nf 1 2 3\n",
+                "v 0 0 0\nv 1 0 0\nv 0 1 0\nf " + " ".join(["1", "2", "3"] * 4000) + "\n", "f 1 2 3\nv 0 0 0\nv 1 0 0\nv 0 1 0\n",
+                obj.replace("\n", "\r\n"), "\x00" * 1000, "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1//1 2//2 3//3\nf a b c\n"]
+    for _ in range(60):
+        ls = list(olines)
+        i = rng.randrange(len(ls))
+        op = rng.randrange(4)
+        if op == 0:
+            ls = ls[:i]
+        elif op == 1:
+            ls[i] = "".join(chr(rng.randrange(1, 256)) for _ in range(rng.randrange(1, 60)))
+        elif op == 2:
+            ls[i] = ls[i] + " 1e999 -7 0"
+        else:
+            del ls[i]
+        variants.append("\n".join(ls))
+    files = []
+    for k, v in enumerate(variants):
+        d = tmp_path / ("m%03d" % k)
+        (d / "meshes").mkdir(parents=True)
+        for name in ("icosphere.obj", "tetra.obj"):
+            shutil.copy(os.path.join(ROOT, "scenes", "meshes", name), str(d / "meshes" / name))
+        (d / "meshes" / "torus.obj").write_bytes(v.encode("latin-1", errors="replace"))
+        (d / "scene.txt").write_text(scene)
+        files.append(str(d / "scene.txt"))
+    r = _run(harness, tmp_path, files)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-4000:])
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
+    loaded, rejected = (int(x) for x in r.stdout.split()[1:4:2])
+    assert loaded >= 3 and rejected >= 8 and loaded + rejected == len(files)
+
+
 def test_oracle_is_clean_under_sanitizers(tmp_path):
     """The CPU oracle itself (test infrastructure, but every parity claim rests on it): every render option,
     the pool trace, the flat kernel and the conversions, with ASan + UBSan watching."""
