@@ -404,7 +404,7 @@ def main():
             "config": {"workload": desc, "scene": scene_path, "resolution": [W, H], "bounces": depth,
                        "rays_per_step": W * H, "sharding": "rows interleaved over %d GPU(s), 1 RCCL %s per frame" % (world, "gather of the owned rows" if args.exchange == "gather" else "reduce"),
                        "live_ray_bounces_per_step": round(live_per_step),
-                       "compaction": ("segmented, wave-autonomous; " + {0: "stable order (ordering=0)", 1: "typed work queues (ordering=1)", 4: "typed ray streams (ordering=4)"}.get(args.ordering, "stable order")) if args.compaction == 0 else "global look-back scan",
+                       "compaction": ("segmented, wave-autonomous; " + {0: "stable order (ordering=0)", 1: "typed work queues (ordering=1)"}.get(args.ordering, "stable order")) if args.compaction == 0 else "global look-back scan",
                        "direct_light": bool(args.direct_light), "streams_per_gpu": S,
                        "warmup_passes": "W steps + %d untimed K-step passes (same launch-group shape as the timed passes; until three in a row agree to 1 %%)" % warm_passes},
             "roofline": roof,

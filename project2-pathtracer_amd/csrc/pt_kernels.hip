@@ -329,9 +329,6 @@ __device__ __forceinline__ int nearest_hit_wide(const GeomRec *lg, const GeomRec
     for (int pass = 0; pass < 2; ++pass) {
         u64 m = pass == 0 ? (cm & boxclusters) : (cm & ~boxclusters);
         while (m) {                                       // per-lane trip count; the wave runs until all lanes are done
-#ifdef PT_CULL_STATS
-            { const unsigned long long act = __ballot(1); if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(act)) { atomicAdd(&g_cull_stats[6], 1ull); atomicAdd(&g_cull_stats[7], (unsigned long long)__popcll(act)); } }
-#endif
             const int c = __builtin_ctzll(m);
             m &= m - 1ull;
             const int first = cl[c].first, count = cl[c].count;      // per-lane LDS reads
@@ -364,13 +361,7 @@ __device__ __forceinline__ int nearest_hit_wide(const GeomRec *lg, const GeomRec
             L = (L & ~0xFFull) | en;
         }
         const uint32_t total = cnt[pass];
-#ifdef PT_CULL_STATS
-        if (pass == 0) { if ((threadIdx.x & 63) == 0) atomicAdd(&g_cull_stats[0], 1ull); atomicAdd(&g_cull_stats[5], (unsigned long long)(cnt[0] + cnt[1])); }
-#endif
         for (uint32_t i = 0; i < total; ++i) {            // per-lane trip count; the wave runs until all lanes are done
-#ifdef PT_CULL_STATS
-            { const unsigned long long act = __ballot(1); if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(act)) { atomicAdd(&g_cull_stats[1 + 2 * pass], 1ull); atomicAdd(&g_cull_stats[2 + 2 * pass], (unsigned long long)__popcll(act)); } }
-#endif
             const int p = (int)((L >> (8u * i)) & 0xFFull);
             const GeomRec *g = tab + p;                   // per-lane gather
             if (hit >= 0) {                               // entered farther than the best exact hit: cannot win or tie
@@ -704,8 +695,6 @@ struct SegArgs {
     uint32_t bank;                   // counter bank of this launch group (the host alternates 0/1)
     const uint32_t *lights;          // direct_light: indices of the emitting primitives, in index order
     uint32_t nlights;
-    uint32_t region_slots, cnt_stride, keep_all;   // typed streams: slots per pool region, stride of the two count arrays,
-                                     //   keep rays without candidates (parity hook)
     int nbc, nsc;                    // many-primitive variant: cube / sphere clusters behind the geometry table
     uint32_t cluster_bytes;          //   and the size of that table (clusters + member ids, multiple of 16)
     CamRec cam;
@@ -1209,253 +1198,6 @@ __global__ __launch_bounds__(kBlock, PT_Q_WAVES) void k_bounce_q(SegArgs a, cons
     }
 }
 
-// ------------------------------------------------------------------ bounce, typed ray streams ----
-// `ordering = 4` (experimental successor of the typed work queues).  The regrouping by candidate type moves from
-// LDS into the pool itself: a ray is stored WITH its candidate mask and nearest candidate (12 dwords), in one of two
-// pool regions by the type of that candidate, and rays without any candidate are never stored at all (they are
-// counted as alive where they are produced, which is what the live counters mean).  A bounce launch then reads dense
-// runs of one type -- exact test on full waves straight from HBM, no queues, no LDS but the tables -- shades the
-// hits, runs the culling pass for the NEW ray on the spot and appends it to the wave's output stream of its type.
-// Bounce 0 is preceded by a generate launch (camera ray + culling pass -> typed streams).  Waves own their segments
-// in both regions and fill them densely like the queue kernel.  Results identical (asserted).
-
-template <bool LAST, bool GEN>
-__global__ __launch_bounds__(kBlock, PT_Q_WAVES) void k_bounce_t(SegArgs a, const GeomRec *__restrict__ geoms,
-                                                                 const MatRec *__restrict__ mats, QTables qt) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint32_t *ctrl = reinterpret_cast<uint32_t *>(smem);   // [0] survivors, [1] emitted (block sums)
-    if (threadIdx.x < 2) ctrl[threadIdx.x] = 0u;
-    GeomRec *lg;
-    MatRec *lm;
-    FaceFrame *lf = reinterpret_cast<FaceFrame *>(smem + q_frames_offset(a.G, a.M));
-    CullRec *lc = reinterpret_cast<CullRec *>(smem + q_cull_offset(a.G, a.M));
-    {
-        uint32_t *fd = reinterpret_cast<uint32_t *>(lf);
-        const uint32_t *fs = reinterpret_cast<const uint32_t *>(qt.frames);
-        for (uint32_t i = threadIdx.x; i < (uint32_t)a.G * 3u * (uint32_t)(sizeof(FaceFrame) / 4); i += blockDim.x) fd[i] = fs[i];
-        uint32_t *cd = reinterpret_cast<uint32_t *>(lc);
-        const uint32_t *cs = reinterpret_cast<const uint32_t *>(qt.cull);
-        for (uint32_t i = threadIdx.x; i < (uint32_t)(qt.nbox + qt.nsph) * (uint32_t)(sizeof(CullRec) / 4); i += blockDim.x) cd[i] = cs[i];
-    }
-    stage_tables(smem, geoms, a.G, mats, a.M, true, lg, lm);        // ends with __syncthreads()
-
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
-    const uint32_t wslot = blockIdx.x * kWaves + wave, nslots = gridDim.x * kWaves;
-    const size_t cap = a.cap;                              // field stride: both regions
-    const uint32_t S = a.seg_slots, R = a.region_slots, CS = a.cnt_stride;
-    uint32_t emitted = 0u, survivors = 0u;
-
-    uint32_t *bank = a.bank ? a.sync->counts_b : a.sync->counts;
-    if (GEN && blockIdx.x == 0 && threadIdx.x < 72) {
-        uint32_t *other = a.bank ? a.sync->counts : a.sync->counts_b;
-        a.sync->totals[threadIdx.x] += other[threadIdx.x];
-        other[threadIdx.x] = 0u;
-        if (threadIdx.x == 0) bank[0] = a.n_rays;
-    }
-    uint32_t boxbits = 0u;
-    for (int j = 0; j < a.G; ++j)
-        if (lg[j].type == 1) boxbits |= 1u << j;
-
-    // input cursor: (type, segment, group) over the wave's segments of both regions; GEN: virtual full segments
-    uint32_t t = 0u, seg = wslot, n = 0u, g = 0u;
-    auto seg_count = [&](uint32_t ty, uint32_t sg) -> uint32_t {
-        if (GEN) {
-            const uint32_t f0 = sg * S;
-            return f0 >= a.n_rays ? 0u : (a.n_rays - f0 < S ? a.n_rays - f0 : S);
-        }
-        return a.cnt_in[ty * CS + sg];
-    };
-    auto seek = [&]() {                                    // first non-empty segment at or after (t, seg)
-        for (;;) {
-            while (seg < a.nseg_in) {
-                n = seg_count(t, seg);
-                if (n) return true;
-                seg += nslots;
-            }
-            if (GEN || t == 1u) return false;
-            t = 1u; seg = wslot;
-        }
-    };
-    bool more = seek();
-    uint32_t osegA = wslot, ofillA = 0u, osegB = wslot, ofillB = 0u;
-    const float kInf = 100000000000000000.0f;
-
-    while (more) {
-        const uint32_t k = g + lane;
-        const bool valid = k < n;
-        f3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(0, 0, 0);
-        uint32_t pv = 0u;
-        bool alive = false;
-        if (GEN) {
-            // ---------------------------------------------------------------- generate
-            if (valid) {
-                const uint32_t ray = seg * S + k;
-                const uint32_t slot = a.batch > 1u ? ray / a.n_own : 0u;
-                const uint32_t local = ray - slot * a.n_own;
-                const uint32_t W = (uint32_t)a.cam.W;
-                const uint32_t lr = local / W, x = local - lr * W;
-                const uint32_t pixel = (lr * (uint32_t)a.cam.row_stride + (uint32_t)a.cam.row_offset) * W + x;
-                camera_ray(a.cam, pixel, a.iteration + slot, o, d);
-                thr = mk(1.0f, 1.0f, 1.0f);
-                pv = pixel | (slot << 24);
-                alive = true;
-            }
-        } else {
-            // ---------------------------------------------------------------- load a dense run of one type, exact test
-            uint32_t mask = 0u;
-            int j = 0xFF;
-            if (valid) {
-                const uint32_t idx = t * R + seg * S + k;
-                __builtin_assume(idx < (1u << 30));
-                const float *in = a.in;
-                o = mk(in[idx], (in + cap)[idx], (in + 2 * cap)[idx]);
-                d = mk((in + 3 * cap)[idx], (in + 4 * cap)[idx], (in + 5 * cap)[idx]);
-                thr = mk((in + 6 * cap)[idx], (in + 7 * cap)[idx], (in + 8 * cap)[idx]);
-                pv = reinterpret_cast<const uint32_t *>(in + 9 * cap)[idx];
-                mask = reinterpret_cast<const uint32_t *>(in + 10 * cap)[idx];
-                j = (int)reinterpret_cast<const uint32_t *>(in + 11 * cap)[idx];
-            }
-            float best = kInf;
-            int hit = -1, face = -1;
-            f3 P = mk(0, 0, 0), N = mk(0, 0, 0);
-            bool active = valid && j != 0xFF;                         // 0xFF: a ray kept without candidates (parity hook only)
-            j &= 31;
-            for (;;) {                                                // one round; more only for the rare rays with rivals
-                const bool jb = (boxbits >> j) & 1u;
-                const GeomRec *gr = lg + j;                           // per-lane gather from the LDS table
-                f3 p = mk(0, 0, 0), nn = mk(0, 0, 0);
-                int fc = -1;
-                float depth = -1.0f;
-                if (__any(active && jb)) { if (active && jb) depth = box_test_face(gr->inv, gr->xf, gr->inside_hits, o, d, p, fc); }
-                if (__any(active && !jb)) { if (active && !jb) depth = sphere_test(gr->inv, gr->xf, o, d, p, nn); }
-                const bool wins = active && depth > -PT_EPSILON && (depth < best || (depth == best && j < hit));
-                if (wins) { best = depth; hit = j; P = p; N = nn; face = fc; }
-                int next_j = -1;
-                if (active && mask != 0u) {
-                    const CullRay cr = make_cull_ray(o, d);
-                    float nt = 3.0e38f;
-                    uint32_t m = mask;
-                    while (m) {
-                        const int jj = __builtin_ctz(m);
-                        m &= m - 1u;
-                        const GeomRec *gb = lg + jj;
-                        float tn;
-                        if ((boxbits >> jj) & 1u) (void)cull_box(gb->bmin, gb->bmax, cr, tn);
-                        else (void)cull_sphere(gb->bmin, gb->bmax, cr, tn);
-                        if (hit >= 0 && tn - gb->slack > best) { mask &= ~(1u << jj); continue; }
-                        if (tn < nt) { nt = tn; next_j = jj; }
-                    }
-                }
-                active = next_j >= 0;
-                if (!__any(active)) break;
-                if (active) { j = next_j; mask &= ~(1u << next_j); }
-            }
-            // ---------------------------------------------------------------- shade the hits
-            if (hit >= 0) {
-                const uint32_t slot = a.batch > 1u ? pv >> 24 : 0u, pixel = pv & a.pix_mask;
-                const MatRec m = lm[lg[hit].mat];
-                if (LAST && !(m.emittance > 0.0f)) {
-                    alive = true;                                     // depth exhausted: alive, contributes 0
-                } else {
-                    const uint32_t iteration = a.iteration + slot;
-                    uint32_t st = lcg_seed(stream_seed(pixel, iteration, 1u + (uint32_t)a.bounce));
-                    st = lcg_next(st); const float u_sel = u01(st);
-                    st = lcg_next(st); const float xi1 = u01(st);
-                    st = lcg_next(st); const float xi2 = u01(st);
-                    f3 L = mk(0.0f, 0.0f, 0.0f);
-                    int code = 4;
-                    const bool hb = (boxbits >> hit) & 1u;
-                    if (__any(hb)) { if (hb) code = scatter_box(m, P, face, lf + 3 * hit, u_sel, xi1, xi2, o, d, thr, L); }
-                    if (__any(!hb)) { if (!hb) code = scatter(m, P, N, u_sel, xi1, xi2, o, d, thr, L); }
-                    if (code == 3) {
-                        float *px = a.batch > 1u ? a.planes + (size_t)slot * a.plane_stride + (size_t)owned_index(a.cam, pixel) * 3
-                                                 : a.image + (size_t)pixel * 3;
-                        (void)unsafeAtomicAdd(px, L.x); (void)unsafeAtomicAdd(px + 1, L.y); (void)unsafeAtomicAdd(px + 2, L.z);
-                        emitted++;
-                    }
-                    alive = code <= 2;
-                }
-            }
-            survivors += (uint32_t)__popcll(__ballot(alive));
-        }
-
-        // -------------------------------------------------------------------- the new ray: culling pass, typed append
-        if (!LAST) {
-            const CullRay cr = make_cull_ray(o, d);
-            float near_t = 3.0e38f;
-            uint32_t mask = 0u, next_j = 0u;
-#pragma unroll 2
-            for (int i = 0; i < qt.nbox; ++i) {
-                const CullRec r = lc[i];
-                float tn;
-                const bool keep = cull_box(r.a, r.b, cr, tn);
-                mask |= keep ? __float_as_uint(r.b[3]) : 0u;
-                const bool nearer = keep && tn < near_t;
-                near_t = nearer ? tn : near_t;
-                next_j = nearer ? __float_as_uint(r.a[3]) : next_j;
-            }
-#pragma unroll 2
-            for (int i = qt.nbox; i < qt.nbox + qt.nsph; ++i) {
-                const CullRec r = lc[i];
-                float tn;
-                const bool keep = cull_sphere(r.a, r.b, cr, tn);
-                mask |= keep ? __float_as_uint(r.b[1]) : 0u;
-                const bool nearer = keep && tn < near_t;
-                near_t = nearer ? tn : near_t;
-                next_j = nearer ? __float_as_uint(r.b[0]) : next_j;
-            }
-            if (!alive) mask = 0u;
-            const bool store = alive && (mask != 0u || a.keep_all != 0u);
-            if (mask == 0u) next_j = 0xFFu;
-            mask &= ~(1u << (next_j & 31u));
-            const bool tob = store && (next_j == 0xFFu || ((boxbits >> next_j) & 1u));
-            const bool tos = store && !tob;
-            const u64 bb = __ballot(tob), sb = __ballot(tos);
-            if (bb | sb) {
-                if (store) {
-                    uint32_t p = tob ? ofillA + wave_rank(bb) : ofillB + wave_rank(sb);
-                    uint32_t sg = tob ? osegA : osegB;
-                    if (p >= S) { p -= S; sg += nslots; }
-                    const uint32_t oi = (tob ? 0u : R) + sg * S + p;
-                    __builtin_assume(oi < (1u << 30));
-                    float *out = a.out;
-                    out[oi] = o.x; (out + cap)[oi] = o.y; (out + 2 * cap)[oi] = o.z;
-                    (out + 3 * cap)[oi] = d.x; (out + 4 * cap)[oi] = d.y; (out + 5 * cap)[oi] = d.z;
-                    (out + 6 * cap)[oi] = thr.x; (out + 7 * cap)[oi] = thr.y; (out + 8 * cap)[oi] = thr.z;
-                    reinterpret_cast<uint32_t *>(out + 9 * cap)[oi] = pv;
-                    reinterpret_cast<uint32_t *>(out + 10 * cap)[oi] = mask;
-                    reinterpret_cast<uint32_t *>(out + 11 * cap)[oi] = next_j;
-                }
-                ofillA += (uint32_t)__popcll(bb);
-                if (ofillA >= S) { if (lane == 0) a.cnt_out[osegA] = S; osegA += nslots; ofillA -= S; }
-                ofillB += (uint32_t)__popcll(sb);
-                if (ofillB >= S) { if (lane == 0) a.cnt_out[CS + osegB] = S; osegB += nslots; ofillB -= S; }
-            }
-        }
-
-        g += 64u;
-        if (g >= n) { g = 0u; n = 0u; seg += nslots; more = seek(); }
-    }
-    // close both output streams: the partly filled segment, then zeros for the wave's unused ones
-    if (!LAST && lane == 0) {
-        uint32_t sg = osegA, c = ofillA;
-        while (sg < a.nseg_out) { a.cnt_out[sg] = c; c = 0u; sg += nslots; }
-        sg = osegB; c = ofillB;
-        while (sg < a.nseg_out) { a.cnt_out[CS + sg] = c; c = 0u; sg += nslots; }
-    }
-
-    for (int sft = 32; sft > 0; sft >>= 1) emitted += __shfl_down(emitted, sft);
-    if (lane == 0) {
-        if (survivors) atomicAdd(&ctrl[0], survivors);
-        if (emitted) atomicAdd(&ctrl[1], emitted);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (!GEN && ctrl[0]) atomicAdd(&bank[a.bounce + 1], ctrl[0]);
-        if (ctrl[1]) atomicAdd(&a.sync->emitted, (u64)ctrl[1]);
-    }
-}
-
 // ------------------------------------------------------------------ fold (batched iterations) ---
 // image[p] = (((image[p] + plane_0[p]) + plane_1[p]) + ...) in iteration order -- the same sum, in the
 // same order, as rendering the iterations one after the other -- and clears the planes for the next
@@ -1600,8 +1342,6 @@ struct pt_context {
     bool seg_mode = true;            // wave-autonomous segmented compaction (cfg.compaction == 0)
     bool cull = true;                // AABB candidate culling in front of the exact tests (cfg.culling == 0)
     bool queue = false;              // typed work-queue kernel (cfg.ordering == 1; LDS geometry, G <= 32, no merging)
-    bool typed = false;              // typed ray streams (cfg.ordering == 4; same scenes): two pool regions by candidate type, 12 fields
-    uint32_t region_slots = 0;       //   slots per region (cap = 2 * region_slots)
     FaceFrame *d_frames = nullptr;   // [G][3] shading frames of the box primitives (k_bounce_q)
     CullRec *d_cull = nullptr;       // bounds for its culling pass, cubes first
     int q_nbox = 0, q_nsph = 0;
@@ -1921,22 +1661,8 @@ int launch_q_t(pt_context *c, const SegArgs &a) {
     return PT_OK;
 }
 
-template <bool LAST, bool GEN>
-int launch_t_t(pt_context *c, const SegArgs &a) {
-    QTables qt;
-    qt.frames = c->d_frames; qt.cull = c->d_cull; qt.nbox = c->q_nbox; qt.nsph = c->q_nsph;
-    hipLaunchKernelGGL((k_bounce_t<LAST, GEN>), dim3(c->grid_bounce), dim3(kBlock), c->lds_bytes, c->stream, a,
-                       (const GeomRec *)c->d_geoms, (const MatRec *)c->d_mats, qt);
-    HIPCHK(hipGetLastError());
-    return PT_OK;
-}
-
 int launch_seg(pt_context *c, const SegArgs &a, bool last, bool gen) {
     Scoped s(c, 1);
-    if (c->typed) {                                       // gen = the generate launch in front of bounce 0
-        if (gen) return launch_t_t<false, true>(c, a);
-        return last ? launch_t_t<true, false>(c, a) : launch_t_t<false, false>(c, a);
-    }
     if (c->queue) {
         if (gen) return last ? launch_q_t<true, true>(c, a) : launch_q_t<false, true>(c, a);
         return last ? launch_q_t<true, false>(c, a) : launch_q_t<false, false>(c, a);
@@ -1960,7 +1686,7 @@ int launch_seg(pt_context *c, const SegArgs &a, bool last, bool gen) {
 uint32_t seg_slots_for(const pt_context *c, uint32_t n_rays) {
     if (c->cfg.chunk_rays > 0) return c->seg_slots;
     // the sparse-work queue drains once per segment (one partly filled group): longer segments there
-    const bool longseg = c->queue || c->typed;
+    const bool longseg = c->queue;
     const uint32_t slots = (uint32_t)c->grid_bounce * kWaves * (longseg ? 2u : 4u);
     uint32_t S = (((n_rays + slots - 1) / slots) + 63u) & ~63u;
     if (S < 192u) S = 192u;
@@ -1987,7 +1713,7 @@ int enqueue_iterations(pt_context *c, uint32_t iteration, uint32_t batch, int st
     const int D = c->cfg.max_depth;
     // The segmented path generates camera rays inside its first bounce launch; k_generate runs only
     // for the look-back variant and for the parity hook that wants the pool before any bounce.
-    const bool fused = c->seg_mode && (stop_after != 0 || c->typed);      // typed streams: the generate launch also serves the hook
+    const bool fused = c->seg_mode && stop_after != 0;
     const uint32_t n_rays = batch * c->n_own;
     if (c->seg_mode) plan_levels(c, n_rays, c->lvl_slots, c->lvl_nseg);
     if (!fused) {
@@ -2003,30 +1729,20 @@ int enqueue_iterations(pt_context *c, uint32_t iteration, uint32_t batch, int st
     }
     const int nb = stop_after < 0 ? D : stop_after;
     if (fused) c->bank ^= 1u;
-    for (int b = (c->typed && fused) ? -1 : 0; b < nb && c->seg_mode; ++b) {     // typed streams: b = -1 is the generate launch
+    for (int b = 0; b < nb && c->seg_mode; ++b) {
         SegArgs a;
-        if (c->typed) {
-            // pool p holds the streams entering bounce p: generate writes pool 0, bounce b reads b & 1 and writes (b+1) & 1
-            a.in = c->pool[(b < 0 ? 1 : b) & 1]; a.out = c->pool[(b + 1) & 1];
-            a.cnt_in = c->d_segcnt[(b < 0 ? 1 : b) & 1]; a.cnt_out = c->d_segcnt[(b + 1) & 1];
-            a.nseg_in = a.nseg_out = c->lvl_nseg[0]; a.seg_slots = c->lvl_slots[0];
-            a.merge = 0u;
-        } else {
-            a.in = c->pool[b & 1]; a.out = c->pool[(b + 1) & 1];
-            a.cnt_in = c->d_segcnt[b & 1]; a.cnt_out = c->d_segcnt[(b + 1) & 1];
-            a.nseg_in = c->lvl_nseg[b]; a.nseg_out = c->lvl_nseg[b + 1]; a.seg_slots = c->lvl_slots[b];
-            a.merge = c->lvl_slots[b + 1] != c->lvl_slots[b] ? 1u : 0u;
-        }
-        a.cap = c->cap; a.image = c->image;
+        a.in = c->pool[b & 1]; a.out = c->pool[(b + 1) & 1]; a.cap = c->cap; a.image = c->image;
         a.G = c->G; a.M = c->M; a.sync = c->d_sync;
-        a.region_slots = c->region_slots; a.cnt_stride = c->nseg + 2u; a.keep_all = stop_after >= 0 ? 1u : 0u;
+        a.cnt_in = c->d_segcnt[b & 1]; a.cnt_out = c->d_segcnt[(b + 1) & 1];
+        a.nseg_in = c->lvl_nseg[b]; a.nseg_out = c->lvl_nseg[b + 1]; a.seg_slots = c->lvl_slots[b];
+        a.merge = c->lvl_slots[b + 1] != c->lvl_slots[b] ? 1u : 0u;
         a.bounce = b; a.iteration = iteration; a.n_own = c->n_own; a.cam = c->cam; a.bank = c->bank;
         a.pix_mask = c->pix_mask;
         a.n_rays = n_rays; a.batch = batch; a.planes = c->d_planes; a.plane_stride = (size_t)c->n_own * 3;
         a.lights = c->d_lights; a.nlights = c->nlights;
         a.nbc = c->nbc; a.nsc = c->nsc; a.cluster_bytes = c->wide ? c->cluster_bytes : 0u;
         const bool last = (stop_after < 0) && (b == D - 1);
-        int rc = launch_seg(c, a, last, c->typed ? b < 0 : b == 0);
+        int rc = launch_seg(c, a, last, b == 0);
         if (rc) return rc;
     }
     if (c->seg_mode && (batch > 1u || c->nee)) {
@@ -2248,11 +1964,10 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     c->seg_mode = (c->cfg.compaction == 0);
     c->cull = (c->cfg.culling == 0) && c->seg_mode;
     c->queue = c->cull && c->cfg.ordering == 1 && c->cfg.geometry_path == 0 && G <= 32 && c->cfg.mode == 0 && c->cfg.merge_floor <= 0;
-    c->typed = c->cull && c->cfg.ordering == 4 && c->cfg.geometry_path == 0 && G <= 32 && c->cfg.mode == 0 && c->cfg.merge_floor <= 0;
     c->geom_lds = (c->cfg.geometry_path == 0);
     if (have_mesh) {
         // meshes are traversed by the stable kernels only
-        c->queue = false; c->typed = false;
+        c->queue = false;
         for (int i = 0; i < G; ++i) {
             if (!mesh_of[i]) continue;
             uint32_t tri_offset = 0;
@@ -2276,7 +1991,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
             pth::set_error("pt_upload_scene: direct_light needs compaction=0, culling=0, geometry_path=0");
             return PT_ERR_ARGUMENT;
         }
-        c->queue = false; c->typed = false;
+        c->queue = false;
         std::vector<uint32_t> lights;
         for (int i = 0; i < G; ++i)
             if (mats[geoms[i].materialid].emittance > 0.0f) lights.push_back((uint32_t)i);
@@ -2288,8 +2003,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
 
     // LDS budget: tables (+ the ray stage of the look-back variant)
     uint32_t tb = tables_bytes(G, M, c->geom_lds);
-    const uint32_t stage_bytes = c->seg_mode ? (c->queue ? q_lds_offset(G, M) - tables_bytes(G, M, true) + kWaves * kQCap * kQFields * (uint32_t)sizeof(float)
-                                                : c->typed ? q_lds_offset(G, M) - tables_bytes(G, M, true) : 0u)
+    const uint32_t stage_bytes = c->seg_mode ? (c->queue ? q_lds_offset(G, M) - tables_bytes(G, M, true) + kWaves * kQCap * kQFields * (uint32_t)sizeof(float) : 0u)
                                              : kBlock * c->rpt * kFields * (uint32_t)sizeof(float);
     if (c->geom_lds && tb + stage_bytes > 160u * 1024u) {   // table too large for LDS: scalar-load path
         if (c->nee) { pth::set_error("pt_upload_scene: direct_light needs the geometry table in LDS (%d primitives do not fit)", G); return PT_ERR_ARGUMENT; }
@@ -2298,7 +2012,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     }
     c->lds_bytes = tb + stage_bytes;
     // 33..256 primitives with the table in LDS: the mask-register / packed-list variant (PT_WIDE=0 turns it off)
-    c->wide = c->cull && c->geom_lds && !c->nee && !c->queue && !c->typed && !have_mesh && c->cfg.mode == 0 && G > 32 && G <= 256;
+    c->wide = c->cull && c->geom_lds && !c->nee && !c->queue && !have_mesh && c->cfg.mode == 0 && G > 32 && G <= 256;
     if (const char *wv = getenv("PT_WIDE")) if (atoi(wv) == 0) c->wide = false;
     // two-level culling of the many-primitive variant: clusters of <= kClusterSize primitives of one type
     std::vector<unsigned char> cluster_blob;
@@ -2401,7 +2115,6 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         const void *fn = c->wide ? reinterpret_cast<const void *>(&k_bounce_seg<true, false, true, false, false, true>)
                        : c->nee ? nee_fns[0]
                        : c->queue ? reinterpret_cast<const void *>(&k_bounce_q<false, false>)
-                       : c->typed ? reinterpret_cast<const void *>(&k_bounce_t<false, false>)
                        : fns[(c->seg_mode ? 4 : 0) + (c->geom_lds ? 0 : 1)];
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, kBlock, c->lds_bytes) != hipSuccess || occ < 1) occ = 2;
         per_cu = occ;
@@ -2437,11 +2150,6 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         const uint32_t max_rays = K * n_own;
         c->nseg = (max_rays + S - 1) / S;                 // S here = the smallest segment size in use
         c->cap = max_rays + 2u * (c->cfg.merge_floor > 0 ? 65536u : 4096u);
-        if (c->typed) {                                   // two regions (cube-first / sphere-first rays), each able to hold every ray
-            if ((uint64_t)c->cap * 2u >= (1ull << 30)) { pth::set_error("pt_upload_scene: ordering=4 supports up to 2^29 rays per launch group"); return PT_ERR_ARGUMENT; }
-            c->region_slots = c->cap;
-            c->cap *= 2u;
-        }
         c->max_chunks = c->nseg;
         if (K > 1u || c->nee) {
             HIPCHK(hipMalloc(&c->d_planes, (size_t)K * n_own * 3 * sizeof(float)));
@@ -2453,8 +2161,8 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         c->grid_bounce = grid;
         plan_levels(c, max_rays, c->lvl_slots, c->lvl_nseg);
         for (int i = 0; i < 2; ++i) {
-            HIPCHK(hipMalloc(&c->d_segcnt[i], (size_t)(c->nseg + 2u) * 2 * sizeof(uint32_t)));       // typed streams: one array per region
-            HIPCHK(hipMemsetAsync(c->d_segcnt[i], 0, (size_t)(c->nseg + 2u) * 2 * sizeof(uint32_t), c->stream));
+            HIPCHK(hipMalloc(&c->d_segcnt[i], (size_t)(c->nseg + 2u) * sizeof(uint32_t)));
+            HIPCHK(hipMemsetAsync(c->d_segcnt[i], 0, (size_t)(c->nseg + 2u) * sizeof(uint32_t), c->stream));
         }
         c->status_words = 0;
     } else {
@@ -2469,7 +2177,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     if (grid < 1) grid = 1;
     c->grid_bounce = grid;
 
-    for (int i = 0; i < 2; ++i) HIPCHK(hipMalloc(&c->pool[i], (size_t)c->cap * (c->typed ? 12 : kFields) * sizeof(float)));
+    for (int i = 0; i < 2; ++i) HIPCHK(hipMalloc(&c->pool[i], (size_t)c->cap * kFields * sizeof(float)));
     HIPCHK(hipMalloc(&c->image_own, (size_t)W * H * 3 * sizeof(float)));
     HIPCHK(hipMemsetAsync(c->image_own, 0, (size_t)W * H * 3 * sizeof(float), c->stream));
     if (!c->image) c->image = c->image_own;
@@ -2480,7 +2188,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     HIPCHK(hipMalloc(&c->d_display, (size_t)W * H * sizeof(uchar4)));
     HIPCHK(hipMemcpy(c->d_geoms, g.data(), (size_t)G * sizeof(GeomRec), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_mats, m.data(), (size_t)M * sizeof(MatRec), hipMemcpyHostToDevice));
-    if (c->queue || c->typed) {
+    if (c->queue) {
         // per box primitive and axis: unit normal + the two tangent frames scatter() would derive per ray; evaluated
         // here with the kernels' own functions (pt_device.hpp is host-callable, same -ffp-contract=off build)
         std::vector<FaceFrame> fr((size_t)G * 3);
@@ -2787,7 +2495,7 @@ int pt_debug_trace_pool(pt_context *c, int iteration, int bounces, int *count, f
     (void)hipFree(scratch);
     SyncBlock after;
     HIPCHK(hipMemcpy(&after, c->d_sync, sizeof after, hipMemcpyDeviceToHost));
-    const bool fused = c->seg_mode && (bounces != 0 || c->typed);
+    const bool fused = c->seg_mode && bounces != 0;
     const uint32_t n = (fused && c->bank) ? after.counts_b[bounces] : after.counts[bounces];
     c->bank = bank_saved;
     HIPCHK(hipMemcpy(c->d_sync, &snapshot, sizeof snapshot, hipMemcpyHostToDevice));
@@ -2802,25 +2510,22 @@ int pt_debug_trace_pool(pt_context *c, int iteration, int bounces, int *count, f
         if (pixel && n) HIPCHK(hipMemcpy(pixel, src + (size_t)9 * c->cap, (size_t)n * 4, hipMemcpyDeviceToHost));
     } else if (n) {
         // segments are dense prefixes in generation order: concatenate them
-        const uint32_t nseg = c->typed ? c->lvl_nseg[0] : c->lvl_nseg[bounces], slots = c->typed ? c->lvl_slots[0] : c->lvl_slots[bounces];
-        const uint32_t regions = c->typed ? 2u : 1u;
-        std::vector<uint32_t> cnt((size_t)nseg * regions);
-        for (uint32_t r = 0; r < regions; ++r)
-            HIPCHK(hipMemcpy(cnt.data() + (size_t)r * nseg, c->d_segcnt[bounces & 1] + (size_t)r * (c->nseg + 2u), (size_t)nseg * 4, hipMemcpyDeviceToHost));
+        const uint32_t nseg = c->lvl_nseg[bounces], slots = c->lvl_slots[bounces];
+        std::vector<uint32_t> cnt(nseg);
+        HIPCHK(hipMemcpy(cnt.data(), c->d_segcnt[bounces & 1], (size_t)nseg * 4, hipMemcpyDeviceToHost));
         std::vector<float> field(c->cap);
         uint64_t total = 0;
-        for (size_t sgi = 0; sgi < cnt.size(); ++sgi) total += cnt[sgi];
+        for (uint32_t sgi = 0; sgi < nseg; ++sgi) total += cnt[sgi];
         if (total != n) { pth::set_error("segment counts (%llu) disagree with the live counter (%u)", (unsigned long long)total, n); return PT_ERR_HIP; }
         for (int f = 0; f < 10; ++f) {
             float *out = f < 9 ? dst[f] : reinterpret_cast<float *>(pixel);
             if (!out) continue;
             HIPCHK(hipMemcpy(field.data(), src + (size_t)f * c->cap, (size_t)c->cap * 4, hipMemcpyDeviceToHost));
             size_t w = 0;
-            for (uint32_t r = 0; r < regions; ++r)
-                for (uint32_t sgi = 0; sgi < nseg; ++sgi) {
-                    memcpy(out + w, field.data() + (size_t)r * c->region_slots + (size_t)sgi * slots, (size_t)cnt[(size_t)r * nseg + sgi] * 4);
-                    w += cnt[(size_t)r * nseg + sgi];
-                }
+            for (uint32_t sgi = 0; sgi < nseg; ++sgi) {
+                memcpy(out + w, field.data() + (size_t)sgi * slots, (size_t)cnt[sgi] * 4);
+                w += cnt[sgi];
+            }
         }
     }
     // direct_light: camera rays carry the count-emission flag implicitly (generation is fused into the

@@ -161,7 +161,7 @@ def test_image_and_live_counts_match_oracle(pt, scene_name, depth, iters):
     assert not np.isnan(img).any()
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(ordering=1), dict(ordering=4), dict(direct_light=1)])
+@pytest.mark.parametrize("kw", [dict(), dict(ordering=1), dict(direct_light=1)])
 def test_long_launch_groups_use_every_slot_bit(pt, kw):
     """Small frames batch up to 128 iterations into one launch group (slot = bits 24..30 of the pixel
     word, bit 31 = the direct-light flag): 150 iterations = one full group + a partial one."""
@@ -190,7 +190,7 @@ def test_accumulation_continues_from_host_image(pt, cornell200):
 
 
 @pytest.mark.parametrize("kw", [dict(geometry_path=1), dict(chunk_rays=64), dict(batch=1), dict(batch=2), dict(batch=3, chunk_rays=100), dict(chunk_rays=64, merge_floor=3000), dict(chunk_rays=64, merge_floor=50, batch=2), dict(chunk_rays=1000), dict(chunk_rays=16, merge_floor=1), dict(chunk_rays=100, merge_floor=7), dict(blocks_per_cu=1),
-                                dict(culling=1), dict(culling=1, geometry_path=1), dict(ordering=1), dict(ordering=1, batch=2), dict(ordering=1, chunk_rays=100, merge_floor=7), dict(ordering=1, batch=1, chunk_rays=64), dict(ordering=1, chunk_rays=128, blocks_per_cu=1), dict(ordering=1, batch=5, blocks_per_cu=2), dict(ordering=4), dict(ordering=4, batch=2), dict(ordering=4, batch=1, chunk_rays=64), dict(ordering=4, chunk_rays=128, blocks_per_cu=1),
+                                dict(culling=1), dict(culling=1, geometry_path=1), dict(ordering=1), dict(ordering=1, batch=2), dict(ordering=1, chunk_rays=100, merge_floor=7), dict(ordering=1, batch=1, chunk_rays=64), dict(ordering=1, chunk_rays=128, blocks_per_cu=1), dict(ordering=1, batch=5, blocks_per_cu=2),
                                 dict(compaction=1), dict(compaction=1, chunk_rays=256), dict(compaction=1, chunk_rays=1024, geometry_path=1)])
 def test_launch_variants_are_bit_identical(pt, cornell200, kw):
     ref = make_tracer(cornell200)
@@ -274,7 +274,7 @@ def test_concurrent_contexts_share_one_device_image(pt, contexts, kw):
     hip.hipFree(dptr)
 
 
-@pytest.mark.parametrize("streams,kw,depth", [(2, dict(ordering=1), 8), (2, dict(ordering=4), 8), (3, dict(), 6), (2, dict(direct_light=1), 6),
+@pytest.mark.parametrize("streams,kw,depth", [(2, dict(ordering=1), 8), (3, dict(), 6), (2, dict(direct_light=1), 6),
                                                (2, dict(row_offset=1, row_stride=2, ordering=1), 6), (4, dict(batch=3), 5)])
 def test_streams_inside_one_context_are_bit_identical(pt, streams, kw, depth):
     """pt_config.streams: the context shards its rows over internal contexts on separate streams sharing one image.
@@ -510,7 +510,7 @@ def test_light_sampling_helpers_bit_exact(pt):
 @pytest.mark.parametrize("scene_name,depth,iters,kw", [
     ("sampleScene", 8, 5, dict()), ("cornell_mirror", 8, 4, dict()), ("cornell_glass_4k", 12, 3, dict()),
     ("cornell_glass_4k", 6, 3, dict(camera_mode=1, antialias=1, aperture=0.25, focal_distance=12.0))])
-@pytest.mark.parametrize("ordering", [1, 4])
+@pytest.mark.parametrize("ordering", [1])
 def test_sparse_work_queue_ordering_is_bit_identical(pt, scene_name, depth, iters, kw, ordering):
     """ordering=1 (typed work queues: one exact test per stage on full waves): same image, same live counts as the
     oracle; the pool holds the same set of rays."""

@@ -15,7 +15,7 @@ from gpu_common import make_tracer, oracle_config, to_product
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("ordering", [0, 1, 4])
+@pytest.mark.parametrize("ordering", [0, 1])
 def test_frame_above_2pow24_pixels_matches_oracle_rows(pt, ordering):
     """4100x4100 = 16.8 Mpx: the pool's pixel word has no room for an iteration slot any more; the
     library renders one iteration per launch with the raw 32-bit pixel index (VERDICT r1 weak #7)."""
@@ -92,7 +92,7 @@ def test_owned_row_exchange_host_and_peer(pt, streams):
         tr.close()
 
 
-@pytest.mark.parametrize("kw", [dict(ordering=1, streams=2), dict(ordering=4, streams=2), dict(ordering=0, streams=2), dict(ordering=1, streams=1),
+@pytest.mark.parametrize("kw", [dict(ordering=1, streams=2), dict(ordering=0, streams=2), dict(ordering=1, streams=1),
                                 dict(direct_light=1, streams=2)])
 def test_headline_launch_variant_full_size_against_oracle_rows(pt, kw):
     """What bench.py times (configs[2] at 1920x1080, ordering=1, streams=2, automatic batching over a
