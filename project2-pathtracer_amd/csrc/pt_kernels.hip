@@ -329,6 +329,9 @@ __device__ __forceinline__ int nearest_hit_wide(const GeomRec *lg, const GeomRec
     for (int pass = 0; pass < 2; ++pass) {
         u64 m = pass == 0 ? (cm & boxclusters) : (cm & ~boxclusters);
         while (m) {                                       // per-lane trip count; the wave runs until all lanes are done
+#ifdef PT_CULL_STATS
+            { const unsigned long long act = __ballot(1); if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(act)) { atomicAdd(&g_cull_stats[6], 1ull); atomicAdd(&g_cull_stats[7], (unsigned long long)__popcll(act)); } }
+#endif
             const int c = __builtin_ctzll(m);
             m &= m - 1ull;
             const int first = cl[c].first, count = cl[c].count;      // per-lane LDS reads
@@ -361,7 +364,13 @@ __device__ __forceinline__ int nearest_hit_wide(const GeomRec *lg, const GeomRec
             L = (L & ~0xFFull) | en;
         }
         const uint32_t total = cnt[pass];
+#ifdef PT_CULL_STATS
+        if (pass == 0) { if ((threadIdx.x & 63) == 0) atomicAdd(&g_cull_stats[0], 1ull); atomicAdd(&g_cull_stats[5], (unsigned long long)(cnt[0] + cnt[1])); }
+#endif
         for (uint32_t i = 0; i < total; ++i) {            // per-lane trip count; the wave runs until all lanes are done
+#ifdef PT_CULL_STATS
+            { const unsigned long long act = __ballot(1); if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(act)) { atomicAdd(&g_cull_stats[1 + 2 * pass], 1ull); atomicAdd(&g_cull_stats[2 + 2 * pass], (unsigned long long)__popcll(act)); } }
+#endif
             const int p = (int)((L >> (8u * i)) & 0xFFull);
             const GeomRec *g = tab + p;                   // per-lane gather
             if (hit >= 0) {                               // entered farther than the best exact hit: cannot win or tie
