@@ -205,3 +205,40 @@ def test_adaptor_shards_rows_over_several_contexts(tmp_path, ngpu, pbo):
     assert np.array_equal(outs[1][0], outs[ngpu][0]) and outs[1][1] == outs[ngpu][1]
     if pbo == "1":
         assert np.array_equal(outs[1][2], outs[ngpu][2])
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "adaptor_probe")), reason="oracle/_ref/adaptor_probe not built")
+@pytest.mark.parametrize("lazy,ngpu", [(1, 1), (8, 1), (3, 2)])
+def test_scene_change_in_the_middle_of_a_frame_keeps_the_samples(tmp_path, lazy, ngpu):
+    """The reference round-trips camera::image on every call, so a caller may change geometry or materials between two
+    iterations of a frame and keeps what was rendered so far.  The adaptor holds the accumulator on the device between
+    observation points: on a content change it must bring the samples home before it rebuilds its device state
+    (ADVICE r1).  Expected = the oracle: iterations 1..2 of scene A, then 3..6 of scene B on top."""
+    import ctypes as C
+    pkg = load_package()
+    scene_path = _small_scene(tmp_path, 64, 48, 6)
+    out = str(tmp_path / "mid.f32")
+    env = dict(os.environ, PT_MODE="pathtrace", PT_MAX_DEPTH="5", PT_LAZY_BATCH=str(lazy), PT_NGPU=str(ngpu), PT_DEVICES=",".join(["0"] * ngpu))
+    r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "adaptor_probe"), scene_path, "6", "3", out], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr
+    got = np.fromfile(out, np.float32).reshape(48, 64, 3)
+    sf = pkg.SceneFile(scene_path)
+    geoms, mats, cam = sf.flatten(0)
+    a = orc.scene_from_pods(geoms, mats, cam)
+    part, _ = orc.render(a, orc.default_config(5), 1, 2)
+    b = orc.scene_from_pods(geoms, mats, cam)
+    b.materials[0].color[0], b.materials[0].color[1], b.materials[0].color[2] = 0.2, 0.9, 0.4
+    # object 5 moved up by 1: rebuild its matrices from the TRS triple the reference's parser read
+    gold = json.load(open(os.path.join(orc.GOLD, "ref_scene_cornell_mirror.json")))["objects"][5]["frames"][0]
+    tr = [orc.f32_from_bits(v) for v in gold["translation"]]
+    ro = [orc.f32_from_bits(v) for v in gold["rotation"]]
+    scl = [orc.f32_from_bits(v) for v in gold["scale"]]
+    tr[1] = float(np.float32(tr[1]) + np.float32(1.0))
+    xf, inv = np.zeros(16, np.float32), np.zeros(16, np.float32)
+    orc.lib().orc_build_transform(orc.vec3(*tr), orc.vec3(*ro), orc.vec3(*scl), orc.fptr(xf), orc.fptr(inv))
+    for k in range(16):
+        b.geoms[5].transform[k] = float(xf[k]); b.geoms[5].inverseTransform[k] = float(inv[k])
+    want, _ = orc.render(b, orc.default_config(5), 3, 4, image=part.copy())
+    assert np.array_equal(got, want)
+    assert not np.array_equal(got, orc.render(a, orc.default_config(5), 1, 6)[0])      # the change is visible

@@ -1,7 +1,8 @@
 """Per-rank cost of the row-sharded render as a function of the shard count, measured on ONE GPU:
 the contexts render only the rows one rank of an N-GPU job would own.  N x the per-step time against the
 1-GPU step time OF THE SAME RUN is the compute-side strong-scaling efficiency (exchange excluded).
-usage: python tools/shard_sim.py [streams=2]   (contexts per rank, as bench.py --streams)"""
+usage: python tools/shard_sim.py [streams=2] [key=value ...]   (contexts per rank, as bench.py --streams; pt_config fields,
+       worlds=8 restricts the shard counts)"""
 import importlib
 import os
 import sys
@@ -11,13 +12,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("project2-pathtracer_amd")
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+KW = {k: int(v) for k, v in (a.split("=") for a in sys.argv[2:])}
+WORLDS = (1, KW.pop("worlds")) if "worlds" in KW else (1, 2, 4, 8)
 sf = pkg.SceneFile(os.path.join(ROOT, "scenes", "cornell_mirror.txt"))
 g, m, cam = sf.flatten(0)
 base = {}
-for world in (1, 2, 4, 8):
+for world in WORLDS:
     trs = []
     for r in range(S):                     # rank 0 of `world`: rows y % (world*S) == r*world
-        tr = pkg.PathTracer(pkg.default_config(max_depth=8, ordering=1, row_offset=r * world, row_stride=world * S))
+        tr = pkg.PathTracer(pkg.default_config(max_depth=8, ordering=1, row_offset=r * world, row_stride=world * S, **(KW if world > 1 else {})))
         tr.upload(g, m, cam)
         tr.set_image(None)
         trs.append(tr)
