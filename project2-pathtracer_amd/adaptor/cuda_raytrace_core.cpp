@@ -22,7 +22,7 @@
 //   * errors print "Cuda error: <what>: <why>." and exit(EXIT_FAILURE) (raytraceKernel.cu:20-26).
 // Options the reference has no channel for come from the environment:
 //   PT_MODE=pathtrace|reference  PT_MAX_DEPTH  PT_CAMERA_MODE  PT_AA  PT_APERTURE  PT_FOCAL_DIST
-//   PT_DIRECT_LIGHT  PT_STREAMS  PT_DEVICE  PT_PBO_IS_DEVICE  PT_SYNC_EVERY_CALL  PT_LAZY_BATCH  PT_NGPU  PT_DEVICES
+//   PT_DIRECT_LIGHT  PT_STREAMS  PT_ORDERING  PT_DEVICE  PT_PBO_IS_DEVICE  PT_SYNC_EVERY_CALL  PT_LAZY_BATCH  PT_NGPU  PT_DEVICES
 //   PT_DUMP_IMAGE=<file> (test hook: camera::image as raw floats after the final iteration)
 #include <cstdio>
 #include <cstdlib>
@@ -147,6 +147,7 @@ void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iteratio
             cfg.focal_distance = env_float("PT_FOCAL_DIST", 0.0f);
             cfg.direct_light = env_int("PT_DIRECT_LIGHT", 0);
             cfg.streams = env_int("PT_STREAMS", 2);
+            cfg.ordering = env_int("PT_ORDERING", 1);         // typed work queues: fastest, results identical
             cfg.row_offset = r;
             cfg.row_stride = ngpu;
             pt_context *c = nullptr;
