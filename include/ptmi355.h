@@ -164,9 +164,8 @@ typedef struct {
     int          ntriangles;
 } pt_mesh;
 /* Copies the meshes; they take effect at the next pt_upload_scene (which builds one BVH per mesh).  nmeshes = 0
- * clears.  A type-2 geom without a registered mesh is skipped, like every MESH in the reference.  Meshes render on
- * the stable kernels (ordering / bvh options are ignored for such scenes); direct_light with an emitting mesh is
- * refused. */
+ * clears.  A type-2 geom without a registered mesh is skipped, like every MESH in the reference.  direct_light with
+ * an emitting mesh is refused. */
 int  pt_set_meshes(pt_context *ctx, const pt_mesh *meshes, int nmeshes);
 
 /* Scene for one frame == the packing cudaRaytraceCore does at src/raytraceKernel.cu:179-206.

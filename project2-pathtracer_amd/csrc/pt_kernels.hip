@@ -925,9 +925,12 @@ __global__ __launch_bounds__(kBlock, PT_Q_WAVES) void k_bounce_q(SegArgs a, cons
         if (threadIdx.x == 0) bank[0] = a.n_rays;
     }
 
-    uint32_t boxbits = 0u;                                 // wave-uniform; G <= 32 on this path
-    for (int j = 0; j < a.G; ++j)
+    uint32_t boxbits = 0u, meshbits = 0u;                  // wave-uniform; G <= 32 on this path
+    for (int j = 0; j < a.G; ++j) {
         if (lg[j].type == 1) boxbits |= 1u << j;
+        else if (lg[j].type == 2 && lg[j].inside_hits != 0) meshbits |= 1u << j;      // a MESH with registered triangles
+    }
+    const uint32_t aabbbits = boxbits | meshbits;         // primitives whose conservative bound is a box
 
     // input cursor: the wave's segments in order, skipping empty ones
     auto seg_count = [&](uint32_t sg) -> uint32_t {
@@ -1100,8 +1103,10 @@ __global__ __launch_bounds__(kBlock, PT_Q_WAVES) void k_bounce_q(SegArgs a, cons
             f3 p = mk(0, 0, 0), nn = mk(0, 0, 0);
             int fc = -1;
             float depth = -1.0f;
+            const bool jm = (meshbits >> j) & 1u;                     // meshes wait on the sphere stack and are tested beside them
             if (__any(active && jb)) { if (active && jb) depth = box_test_face(gr->inv, gr->xf, gr->inside_hits, o, d, p, fc); }
-            if (__any(active && !jb)) { if (active && !jb) depth = sphere_test(gr->inv, gr->xf, o, d, p, nn); }
+            if (__any(active && !jb && !jm)) { if (active && !jb && !jm) depth = sphere_test(gr->inv, gr->xf, o, d, p, nn); }
+            if (meshbits != 0u && __any(active && jm)) { if (active && jm) depth = mesh_test(gr, o, d, p, nn); }
             // nearest-hit update of the reference loop (first strictly nearer wins; ties to the lower index)
             const bool wins = active && depth > -PT_EPSILON && (depth < best || (depth == best && j < hit));
             if (wins) { best = depth; hit = j; P = p; N = nn; face = fc; }
@@ -1116,7 +1121,7 @@ __global__ __launch_bounds__(kBlock, PT_Q_WAVES) void k_bounce_q(SegArgs a, cons
                     m &= m - 1u;
                     const GeomRec *gb = lg + jj;
                     float tn;
-                    if ((boxbits >> jj) & 1u) (void)cull_box(gb->bmin, gb->bmax, cr, tn);
+                    if ((aabbbits >> jj) & 1u) (void)cull_box(gb->bmin, gb->bmax, cr, tn);
                     else (void)cull_sphere(gb->bmin, gb->bmax, cr, tn);
                     if (hit >= 0 && tn - gb->slack > best) { mask &= ~(1u << jj); continue; }
                     if (tn < nt) { nt = tn; next_j = jj; }
@@ -1975,8 +1980,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     c->queue = c->cull && c->cfg.ordering == 1 && c->cfg.geometry_path == 0 && G <= 32 && c->cfg.mode == 0 && c->cfg.merge_floor <= 0;
     c->geom_lds = (c->cfg.geometry_path == 0);
     if (have_mesh) {
-        // meshes are traversed by the stable kernels only
-        c->queue = false;
+        // meshes: stable kernels and the typed work queues (where they share the spheres' stack)
         for (int i = 0; i < G; ++i) {
             if (!mesh_of[i]) continue;
             uint32_t tri_offset = 0;
@@ -2212,7 +2216,8 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         auto bits = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
         for (int pass = 1; pass >= 0; --pass)
             for (int i = 0; i < G; ++i) {
-                if (g[i].type != pass) continue;
+                const bool boxlike = g[i].type == 1 || (g[i].type == 2 && g[i].inside_hits != 0);       // cubes and meshes: an AABB
+                if (pass == 1 ? !boxlike : g[i].type != 0) continue;
                 CullRec r;
                 memset(&r, 0, sizeof r);
                 if (pass == 1) {
@@ -2225,7 +2230,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
                 cr.push_back(r);
             }
         c->q_nbox = 0; c->q_nsph = 0;
-        for (int i = 0; i < G; ++i) { if (g[i].type == 1) c->q_nbox++; else if (g[i].type == 0) c->q_nsph++; }
+        for (int i = 0; i < G; ++i) { if (g[i].type == 1 || (g[i].type == 2 && g[i].inside_hits != 0)) c->q_nbox++; else if (g[i].type == 0) c->q_nsph++; }
         if (cr.empty()) cr.emplace_back();
         HIPCHK(hipMalloc(&c->d_cull, cr.size() * sizeof(CullRec)));
         HIPCHK(hipMemcpy(c->d_cull, cr.data(), cr.size() * sizeof(CullRec), hipMemcpyHostToDevice));
