@@ -889,9 +889,10 @@ struct QTables {
     int nbox, nsph;
 };
 
-template <bool LAST, bool GEN>
-__global__ __launch_bounds__(kBlock, PT_Q_WAVES) void k_bounce_q(SegArgs a, const GeomRec *__restrict__ geoms,
-                                                                 const MatRec *__restrict__ mats, QTables qt) {
+// MESH: the scene holds MESH primitives with triangles (their BVH traversal needs registers the common variant must not pay for)
+template <bool LAST, bool GEN, bool MESH = false>
+__global__ __launch_bounds__(kBlock, MESH ? 4 : PT_Q_WAVES) void k_bounce_q(SegArgs a, const GeomRec *__restrict__ geoms,
+                                                                            const MatRec *__restrict__ mats, QTables qt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *ctrl = reinterpret_cast<uint32_t *>(smem);   // [0] survivors, [1] emitted (block sums)
     if (threadIdx.x < 2) ctrl[threadIdx.x] = 0u;
@@ -928,7 +929,7 @@ __global__ __launch_bounds__(kBlock, PT_Q_WAVES) void k_bounce_q(SegArgs a, cons
     uint32_t boxbits = 0u, meshbits = 0u;                  // wave-uniform; G <= 32 on this path
     for (int j = 0; j < a.G; ++j) {
         if (lg[j].type == 1) boxbits |= 1u << j;
-        else if (lg[j].type == 2 && lg[j].inside_hits != 0) meshbits |= 1u << j;      // a MESH with registered triangles
+        else if (MESH && lg[j].type == 2 && lg[j].inside_hits != 0) meshbits |= 1u << j;      // a MESH with registered triangles
     }
     const uint32_t aabbbits = boxbits | meshbits;         // primitives whose conservative bound is a box
 
@@ -1103,10 +1104,10 @@ __global__ __launch_bounds__(kBlock, PT_Q_WAVES) void k_bounce_q(SegArgs a, cons
             f3 p = mk(0, 0, 0), nn = mk(0, 0, 0);
             int fc = -1;
             float depth = -1.0f;
-            const bool jm = (meshbits >> j) & 1u;                     // meshes wait on the sphere stack and are tested beside them
+            const bool jm = MESH && ((meshbits >> j) & 1u);            // meshes wait on the sphere stack and are tested beside them
             if (__any(active && jb)) { if (active && jb) depth = box_test_face(gr->inv, gr->xf, gr->inside_hits, o, d, p, fc); }
             if (__any(active && !jb && !jm)) { if (active && !jb && !jm) depth = sphere_test(gr->inv, gr->xf, o, d, p, nn); }
-            if (meshbits != 0u && __any(active && jm)) { if (active && jm) depth = mesh_test(gr, o, d, p, nn); }
+            if (MESH) { if (__any(active && jm)) { if (active && jm) depth = mesh_test(gr, o, d, p, nn); } }
             // nearest-hit update of the reference loop (first strictly nearer wins; ties to the lower index)
             const bool wins = active && depth > -PT_EPSILON && (depth < best || (depth == best && j < hit));
             if (wins) { best = depth; hit = j; P = p; N = nn; face = fc; }
@@ -1356,6 +1357,7 @@ struct pt_context {
     bool seg_mode = true;            // wave-autonomous segmented compaction (cfg.compaction == 0)
     bool cull = true;                // AABB candidate culling in front of the exact tests (cfg.culling == 0)
     bool queue = false;              // typed work-queue kernel (cfg.ordering == 1; LDS geometry, G <= 32, no merging)
+    bool queue_mesh = false;         //   its variant with mesh traversal (scene has MESH primitives with triangles)
     FaceFrame *d_frames = nullptr;   // [G][3] shading frames of the box primitives (k_bounce_q)
     CullRec *d_cull = nullptr;       // bounds for its culling pass, cubes first
     int q_nbox = 0, q_nsph = 0;
@@ -1669,8 +1671,12 @@ template <bool LAST, bool GEN>
 int launch_q_t(pt_context *c, const SegArgs &a) {
     QTables qt;
     qt.frames = c->d_frames; qt.cull = c->d_cull; qt.nbox = c->q_nbox; qt.nsph = c->q_nsph;
-    hipLaunchKernelGGL((k_bounce_q<LAST, GEN>), dim3(c->grid_bounce), dim3(kBlock), c->lds_bytes, c->stream, a,
-                       (const GeomRec *)c->d_geoms, (const MatRec *)c->d_mats, qt);
+    if (c->queue_mesh)
+        hipLaunchKernelGGL((k_bounce_q<LAST, GEN, true>), dim3(c->grid_bounce), dim3(kBlock), c->lds_bytes, c->stream, a,
+                           (const GeomRec *)c->d_geoms, (const MatRec *)c->d_mats, qt);
+    else
+        hipLaunchKernelGGL((k_bounce_q<LAST, GEN>), dim3(c->grid_bounce), dim3(kBlock), c->lds_bytes, c->stream, a,
+                           (const GeomRec *)c->d_geoms, (const MatRec *)c->d_mats, qt);
     HIPCHK(hipGetLastError());
     return PT_OK;
 }
@@ -1978,9 +1984,11 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     c->seg_mode = (c->cfg.compaction == 0);
     c->cull = (c->cfg.culling == 0) && c->seg_mode;
     c->queue = c->cull && c->cfg.ordering == 1 && c->cfg.geometry_path == 0 && G <= 32 && c->cfg.mode == 0 && c->cfg.merge_floor <= 0;
+    c->queue_mesh = false;
     c->geom_lds = (c->cfg.geometry_path == 0);
     if (have_mesh) {
         // meshes: stable kernels and the typed work queues (where they share the spheres' stack)
+        c->queue_mesh = c->queue;
         for (int i = 0; i < G; ++i) {
             if (!mesh_of[i]) continue;
             uint32_t tri_offset = 0;
@@ -2127,7 +2135,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         int occ = 0;
         const void *fn = c->wide ? reinterpret_cast<const void *>(&k_bounce_seg<true, false, true, false, false, true>)
                        : c->nee ? nee_fns[0]
-                       : c->queue ? reinterpret_cast<const void *>(&k_bounce_q<false, false>)
+                       : c->queue ? (c->queue_mesh ? reinterpret_cast<const void *>(&k_bounce_q<false, false, true>) : reinterpret_cast<const void *>(&k_bounce_q<false, false>))
                        : fns[(c->seg_mode ? 4 : 0) + (c->geom_lds ? 0 : 1)];
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, kBlock, c->lds_bytes) != hipSuccess || occ < 1) occ = 2;
         per_cu = occ;
