@@ -21,6 +21,9 @@ def main():
     sf = pkg.SceneFile(scene)
     g, m, cam = sf.flatten(0)
     tr = pkg.PathTracer(pkg.default_config(max_depth=depth, ordering=1, direct_light=direct))
+    meshes = sf.meshes()
+    if meshes:
+        tr.set_meshes(meshes)
     tr.upload(g, m, cam)
     tr.set_image(None)
     t0 = time.time()
