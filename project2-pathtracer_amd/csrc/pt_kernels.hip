@@ -295,7 +295,7 @@ __device__ __forceinline__ int nearest_hit_culled(const GeomRec *lg, const GeomR
 // tests the members' own bounds through a per-lane gather from the LDS table, appending candidates to two packed
 // per-lane lists (8 bits per entry, up to 8 entries per type, nearest candidate moved to the front).  The exact
 // loops then run ONCE over the lists.  A wave in which any lane has more than 8 candidates of a type takes the
-// block-wise path, so the result is always the reference's.  Cluster boxes are unions of the members' conservative
+// brute-force reference loop, so the result is always the reference's.  Cluster boxes are unions of the members' conservative
 // bounds, so a primitive the exact test can hit is always reached.
 #ifndef PT_CLUSTER
 #define PT_CLUSTER 4                                  // preferred members per cluster; the host grows it until <= 64 clusters
@@ -350,7 +350,7 @@ __device__ __forceinline__ int nearest_hit_wide(const GeomRec *lg, const GeomRec
             }
         }
     }
-    if (__any(overflow)) return nearest_hit_culled<GEOM_LDS>(lg, gg, G, o, d, tbest, P, N);
+    if (__any(overflow)) return nearest_hit(tab, G, o, d, tbest, P, N);      // rare: the reference loop itself (brute force)
     float best = 100000000000000000.0f;
     int hit = -1;
 #pragma unroll
