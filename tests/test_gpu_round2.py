@@ -128,3 +128,58 @@ def test_bench_two_ranks_started_plainly_gloo_rehearsal(pt):
     assert res["n_gpus"] == 2 and res["steps"] == 4 and res["value"] > 0 and res["scaling"] == "strong"
     # self-consistent line: frac (4 decimals) = algorithmic bytes per step / ms_per_step / 8 TB/s
     assert res["roofline"]["frac"] == pytest.approx(res["roofline"]["algorithmic_bytes_per_step"] / (res["ms_per_step"] * 1e-3) / 8e12, abs=1e-4)
+
+
+def _subset_scene(name, keep, w, h):
+    base = orc.load_golden_scene(name).with_resolution(w, h)
+    return orc.Scene([base.geoms[i] for i in keep], base.materials, base.camera)
+
+
+@pytest.mark.parametrize("label,keep", [
+    ("32 mixed primitives (bit 31 of the mask, many rivals per ray)", list(range(6)) + list(range(6, 110, 4))),
+    ("cubes only", [i for i in range(0, 64) if i < 6 or i % 2 == 1][:32]),
+    ("spheres only (no enclosing room)", [i for i in range(6, 70) if i % 2 == 0][:32]),
+    ("one sphere", [6]),
+])
+@pytest.mark.parametrize("kw", [dict(ordering=1), dict(ordering=1, streams=2, batch=3), dict(ordering=0)])
+def test_queue_kernel_on_cluttered_scenes(pt, label, keep, kw):
+    """The typed work queues on scenes that are nothing like the Cornell box: up to the 32 primitives the kernel takes, one
+    type missing altogether, rays with many rival candidates (the in-place extra rounds), mirrors and glass."""
+    sc = _subset_scene("random256", keep, 160, 120)
+    assert sc.G == len(keep) <= 32
+    depth, iters = 7, 3
+    tr = make_tracer(sc, depth=depth, **kw)
+    tr.set_image(None)
+    tr.render(1, iters)
+    want, live = orc.render(sc, oracle_config(depth), 1, iters)
+    st = tr.stats()
+    assert [st.live[k] for k in range(depth + 1)] == [int(v) for v in live], label
+    assert np.array_equal(tr.image(), want), label
+    if kw.get("streams", 1) == 1:
+        n, arrs, pix = tr.trace_pool(2, 4)
+        on, oarrs, opix = orc.trace_pool(sc, oracle_config(depth), 2, 4)
+        order = np.argsort(pix, kind="stable")
+        assert n == on and np.array_equal(pix[order], opix) and all(np.array_equal(a[order], b) for a, b in zip(arrs, oarrs))
+    tr.close()
+
+
+@pytest.mark.parametrize("ordering", [0, 1])
+def test_depth_64_and_rays_that_all_miss(pt, ordering):
+    """max_depth = 64 (the ABI's limit) on the mirror box, and a camera that looks away from everything"""
+    sc = orc.load_golden_scene("cornell_mirror").with_resolution(64, 48)
+    tr = make_tracer(sc, depth=64, ordering=ordering)
+    tr.set_image(None)
+    tr.render(1, 2)
+    want, live = orc.render(sc, oracle_config(64), 1, 2)
+    st = tr.stats()
+    assert [st.live[k] for k in range(65)] == [int(v) for v in live]
+    assert np.array_equal(tr.image(), want)
+    tr.close()
+    away = orc.load_golden_scene("sampleScene").with_resolution(37, 5)
+    away.camera.view[2] = 1.0
+    tr = make_tracer(away, depth=8, ordering=ordering)
+    tr.set_image(None)
+    tr.render(1, 3)
+    st = tr.stats()
+    assert st.live[0] == 3 * 37 * 5 and st.live[1] == 0 and not tr.image().any()
+    tr.close()

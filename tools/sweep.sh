@@ -9,7 +9,7 @@ lab=sys.argv[1]
 for l in open("gpurun_out/sweep_%s.log"%lab):
     if l.startswith("{"):
         d=json.loads(l); r=d.get("roofline") or {}
-        print(lab, "Mray/s", d["value"], "ms/step", d["ms_per_step"], "frac", r.get("frac"), "avg_us", r.get("avg_launch_us"))
+        print(lab, "Mray/s", d["value"], "ms/step", d["ms_per_step"], "frac", r.get("frac"), "avg_us", (r.get("kernel_events") or {}).get("avg_launch_us"))
         break
 else:
     print(lab, "FAILED"); print(open("gpurun_out/sweep_%s.log"%lab).read()[-600:])
