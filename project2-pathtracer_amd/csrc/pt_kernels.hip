@@ -697,6 +697,8 @@ struct SegArgs {
     uint32_t n_own;                  // GEN: rays of bounce 0 come from the camera, not from the pool
     uint32_t n_rays;                 // = batch * n_own: `batch` consecutive iterations share one launch
     uint32_t batch;                  // ray id = slot * n_own + local; the pool's pixel word is slot<<24 | pixel
+    uint32_t pool_bytes;             // queue kernel: size of one pool in bytes when it is below 4 GiB (buffer addressing: one
+                                     //   32-bit lane offset + a scalar field offset per access), else 0 (64-bit flat addresses)
     uint32_t pix_mask;               // 0xFFFFFF while the pixel word carries slot/flag bits; 0xFFFFFFFF for frames above
                                      //   2^24 pixels (then batch == 1, no direct_light: the word is the raw pixel index)
     float *planes;                   // batch > 1: one accumulator plane per in-flight iteration slot
@@ -915,6 +917,19 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : PT_Q_WAVES) void k_bounce_q(SegA
     const uint32_t wslot = blockIdx.x * kWaves + wave, nslots = gridDim.x * kWaves;
     const size_t cap = a.cap;
     const uint32_t S = a.seg_slots;
+    // pool accesses: with a pool below 4 GiB every load / store is `buffer_* v, v_off, s[rsrc], s_field offen` -- one 32-bit
+    // lane offset per ray and a scalar offset per field instead of a 64-bit vector address per access
+    const bool ub = a.pool_bytes != 0u;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in), 0, a.pool_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.pool_bytes, 0x00020000);
+    const uint32_t cap4 = (uint32_t)cap * 4u;
+    auto ldf = [&](uint32_t f, uint32_t idx) -> float {
+        return ub ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in, idx * 4u, f * cap4, 0)) : (a.in + (size_t)f * cap)[idx];
+    };
+    auto stf = [&](uint32_t f, uint32_t idx, float v) {
+        if (ub) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out, idx * 4u, f * cap4, 0);
+        else (a.out + (size_t)f * cap)[idx] = v;
+    };
     uint32_t emitted = 0u, survivors = 0u;
     float *q = reinterpret_cast<float *>(smem + q_lds_offset(a.G, a.M)) + (size_t)wave * kQCap * kQFields;
 
@@ -955,7 +970,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : PT_Q_WAVES) void k_bounce_q(SegA
         if (!GEN && fresh_left && lane < 12u) {
             const uint32_t ray = seg * S + g + (lane & 1u) * 32u;
             __builtin_assume(ray < (1u << 29));
-            if (g + (lane & 1u) * 32u < n) warm = (a.in + (size_t)(lane >> 1) * cap)[ray];
+            if (g + (lane & 1u) * 32u < n) warm = ldf(lane >> 1, ray);
         }
     };
     warm_up();
@@ -992,9 +1007,8 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : PT_Q_WAVES) void k_bounce_q(SegA
                     idx = pixel | (slot << 24);                       // bounce 0 carries the pixel word itself
                 } else {
                     __builtin_assume(ray < (1u << 29));
-                    const float *in = a.in;
-                    o = mk(in[ray], (in + cap)[ray], (in + 2 * cap)[ray]);
-                    d = mk((in + 3 * cap)[ray], (in + 4 * cap)[ray], (in + 5 * cap)[ray]);
+                    o = mk(ldf(0, ray), ldf(1, ray), ldf(2, ray));
+                    d = mk(ldf(3, ray), ldf(4, ray), ldf(5, ray));
                     idx = ray;
                 }
             }
@@ -1087,9 +1101,8 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : PT_Q_WAVES) void k_bounce_q(SegA
             if (GEN) { pv = idx; thr = mk(1.0f, 1.0f, 1.0f); }
             else {
                 __builtin_assume(idx < (1u << 29));
-                const float *in = a.in;
-                thr = mk((in + 6 * cap)[idx], (in + 7 * cap)[idx], (in + 8 * cap)[idx]);
-                pv = reinterpret_cast<const uint32_t *>(in + 9 * cap)[idx];
+                thr = mk(ldf(6, idx), ldf(7, idx), ldf(8, idx));
+                pv = __float_as_uint(ldf(9, idx));
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -1179,11 +1192,10 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : PT_Q_WAVES) void k_bounce_q(SegA
                 p = p >= S ? p - S : p;
                 const uint32_t oi = sg * S + p;
                 __builtin_assume(oi < (1u << 29));
-                float *out = a.out;
-                out[oi] = o.x; (out + cap)[oi] = o.y; (out + 2 * cap)[oi] = o.z;
-                (out + 3 * cap)[oi] = d.x; (out + 4 * cap)[oi] = d.y; (out + 5 * cap)[oi] = d.z;
-                (out + 6 * cap)[oi] = thr.x; (out + 7 * cap)[oi] = thr.y; (out + 8 * cap)[oi] = thr.z;
-                reinterpret_cast<uint32_t *>(out + 9 * cap)[oi] = pv;
+                stf(0, oi, o.x); stf(1, oi, o.y); stf(2, oi, o.z);
+                stf(3, oi, d.x); stf(4, oi, d.y); stf(5, oi, d.z);
+                stf(6, oi, thr.x); stf(7, oi, thr.y); stf(8, oi, thr.z);
+                stf(9, oi, __uint_as_float(pv));
             }
             ofill += na;
             if (ofill >= S) {
@@ -1758,6 +1770,7 @@ int enqueue_iterations(pt_context *c, uint32_t iteration, uint32_t batch, int st
         a.merge = c->lvl_slots[b + 1] != c->lvl_slots[b] ? 1u : 0u;
         a.bounce = b; a.iteration = iteration; a.n_own = c->n_own; a.cam = c->cam; a.bank = c->bank;
         a.pix_mask = c->pix_mask;
+        { const uint64_t pb = (uint64_t)c->cap * kFields * sizeof(float); a.pool_bytes = (c->queue && pb < (1ull << 32) && !getenv("PT_FLAT_POOL")) ? (uint32_t)pb : 0u; }      // PT_FLAT_POOL: A/B switch
         a.n_rays = n_rays; a.batch = batch; a.planes = c->d_planes; a.plane_stride = (size_t)c->n_own * 3;
         a.lights = c->d_lights; a.nlights = c->nlights;
         a.nbc = c->nbc; a.nsc = c->nsc; a.cluster_bytes = c->wide ? c->cluster_bytes : 0u;
