@@ -1107,43 +1107,61 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : PT_Q_WAVES) void k_bounce_q(SegA
         }
         __builtin_amdgcn_wave_barrier();
         PT_MARK("exact_begin");
-        float best = kInf;
-        int hit = -1, face = -1;
+        // One exact test per popped ray: the queue's type for every lane (jb / jm are per lane only for meshes, which
+        // share the spheres' stack).  Nearest-hit update of the reference loop: first strictly nearer wins, ties to the
+        // lower index -- trivial for the first candidate.
+        float best;
+        int hit, face = -1;
         f3 P = mk(0, 0, 0), N = mk(0, 0, 0);
-        bool active = valid;
-        for (;;) {                                                    // one round; more only for the rare rays with rivals
-            const bool jb = (boxbits >> j) & 1u;
+        {
             const GeomRec *gr = lg + j;                               // per-lane gather from the LDS table
-            f3 p = mk(0, 0, 0), nn = mk(0, 0, 0);
-            int fc = -1;
             float depth = -1.0f;
-            const bool jm = MESH && ((meshbits >> j) & 1u);            // meshes wait on the sphere stack and are tested beside them
-            if (__any(active && jb)) { if (active && jb) depth = box_test_face(gr->inv, gr->xf, gr->inside_hits, o, d, p, fc); }
-            if (__any(active && !jb && !jm)) { if (active && !jb && !jm) depth = sphere_test(gr->inv, gr->xf, o, d, p, nn); }
-            if (MESH) { if (__any(active && jm)) { if (active && jm) depth = mesh_test(gr, o, d, p, nn); } }
-            // nearest-hit update of the reference loop (first strictly nearer wins; ties to the lower index)
-            const bool wins = active && depth > -PT_EPSILON && (depth < best || (depth == best && j < hit));
-            if (wins) { best = depth; hit = j; P = p; N = nn; face = fc; }
-            // further candidates: drop those entered farther than the best hit, take the nearest of the rest
-            int next_j = -1;
-            if (active && mask != 0u) {
-                const CullRay cr = make_cull_ray(o, d);
-                float nt = 3.0e38f;
-                uint32_t m = mask;
-                while (m) {
-                    const int jj = __builtin_ctz(m);
-                    m &= m - 1u;
-                    const GeomRec *gb = lg + jj;
-                    float tn;
-                    if ((aabbbits >> jj) & 1u) (void)cull_box(gb->bmin, gb->bmax, cr, tn);
-                    else (void)cull_sphere(gb->bmin, gb->bmax, cr, tn);
-                    if (hit >= 0 && tn - gb->slack > best) { mask &= ~(1u << jj); continue; }
-                    if (tn < nt) { nt = tn; next_j = jj; }
-                }
+            const bool jm = MESH && ((meshbits >> j) & 1u);
+            if (isb) { if (valid) depth = box_test_face(gr->inv, gr->xf, gr->inside_hits, o, d, P, face); }
+            else {
+                if (!MESH || __any(valid && !jm)) { if (valid && !jm) depth = sphere_test(gr->inv, gr->xf, o, d, P, N); }
+                if (MESH) { if (__any(valid && jm)) { if (valid && jm) depth = mesh_test(gr, o, d, P, N); } }
             }
-            active = next_j >= 0;
-            if (!__any(active)) break;
-            if (active) { j = next_j; mask &= ~(1u << next_j); }
+            const bool wins = valid && depth > -PT_EPSILON && depth < kInf;
+            best = wins ? depth : kInf;
+            hit = wins ? j : -1;
+        }
+        // The rare rays (0.04 % in the Cornell box) with rivals: candidates entered farther than the best hit are dropped,
+        // the nearest of the rest is tested on the spot, until no lane has one left.
+        if (__any(valid && mask != 0u)) {
+            bool active = valid;
+            for (;;) {
+                int next_j = -1;
+                if (active && mask != 0u) {
+                    const CullRay cr = make_cull_ray(o, d);
+                    float nt = 3.0e38f;
+                    uint32_t m = mask;
+                    while (m) {
+                        const int jj = __builtin_ctz(m);
+                        m &= m - 1u;
+                        const GeomRec *gb = lg + jj;
+                        float tn;
+                        if ((aabbbits >> jj) & 1u) (void)cull_box(gb->bmin, gb->bmax, cr, tn);
+                        else (void)cull_sphere(gb->bmin, gb->bmax, cr, tn);
+                        if (hit >= 0 && tn - gb->slack > best) { mask &= ~(1u << jj); continue; }
+                        if (tn < nt) { nt = tn; next_j = jj; }
+                    }
+                }
+                active = next_j >= 0;
+                if (!__any(active)) break;
+                if (active) { j = next_j; mask &= ~(1u << next_j); }
+                const bool jb = (boxbits >> j) & 1u;
+                const bool jm = MESH && ((meshbits >> j) & 1u);
+                const GeomRec *gr = lg + j;
+                f3 p = mk(0, 0, 0), nn = mk(0, 0, 0);
+                int fc = -1;
+                float depth = -1.0f;
+                if (__any(active && jb)) { if (active && jb) depth = box_test_face(gr->inv, gr->xf, gr->inside_hits, o, d, p, fc); }
+                if (__any(active && !jb && !jm)) { if (active && !jb && !jm) depth = sphere_test(gr->inv, gr->xf, o, d, p, nn); }
+                if (MESH) { if (__any(active && jm)) { if (active && jm) depth = mesh_test(gr, o, d, p, nn); } }
+                const bool wins = active && depth > -PT_EPSILON && (depth < best || (depth == best && j < hit));
+                if (wins) { best = depth; hit = j; P = p; N = nn; face = fc; }
+            }
         }
         PT_MARK("exact_end");
         const bool shade = hit >= 0;
