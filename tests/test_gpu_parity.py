@@ -370,7 +370,8 @@ def test_full_size_properties_1080p(pt):
     assert np.array_equal(got[rows], a[rows])
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(batch=2, chunk_rays=100), dict(geometry_path=1), dict(culling=1), dict(streams=2), dict(direct_light=1)])
+@pytest.mark.parametrize("kw", [dict(), dict(batch=2, chunk_rays=100), dict(geometry_path=1), dict(culling=1), dict(streams=2), dict(direct_light=1),
+                                dict(ordering=1), dict(ordering=1, batch=3, chunk_rays=128), dict(ordering=1, streams=2)])
 def test_many_primitives_scene_matches_oracle(pt, kw):
     """BASELINE config 4's scene (256 spheres+cubes incl. rotated cubes, mirrors, glass): the two-level
     candidate culling must never change the nearest hit."""
@@ -385,6 +386,9 @@ def test_many_primitives_scene_matches_oracle(pt, kw):
     if kw.get("streams", 1) == 1:
         n, arrs, pix = tr.trace_pool(2, 3)
         on, oarrs, opix = orc.trace_pool(sc, oracle_config(8, **okw), 2, 3)
+        if kw.get("ordering"):             # the typed work queues keep the set of rays, not their order
+            order = np.argsort(pix, kind="stable")
+            pix, arrs = pix[order], [x[order] for x in arrs]
         assert n == on and np.array_equal(pix, opix) and all(np.array_equal(a, b) for a, b in zip(arrs, oarrs))
 
 
@@ -435,6 +439,12 @@ def test_config4_and_config5_full_size_slices(pt):
     want, _ = orc.render(c4, oracle_config(8, **sh_cfg), 1, 1)
     rows = np.arange(1080) % 270 == 11
     assert np.array_equal(full[rows], want[rows])
+    # what bench.py --workload c4 times: the many-primitive typed work queues, two contexts, batched
+    trq = make_tracer(c4, ordering=1, streams=2)
+    trq.set_image(None); trq.render(1, 1)
+    stq = trq.stats()
+    assert np.array_equal(trq.image(), full) and [stq.live[k] for k in range(9)] == [st.live[k] for k in range(9)]
+    trq.close()
     n, arrs, pix = tr.trace_pool(1, 3)
     assert np.all(np.diff(pix.astype(np.int64)) > 0)
 
@@ -479,13 +489,13 @@ def _scaled_scene(name, factor, w, h):
 
 
 @pytest.mark.parametrize("factor", [0.05, 1.0, 37.0, 1000.0])
-@pytest.mark.parametrize("name", ["sampleScene", "random256"])
-def test_culling_is_conservative_at_other_scene_scales(pt, name, factor):
+@pytest.mark.parametrize("name,ordering", [("sampleScene", 0), ("random256", 0), ("random256", 1)])
+def test_culling_is_conservative_at_other_scene_scales(pt, name, ordering, factor):
     """The culling margins are absolute + relative; RAY_BIAS / the sphere pull-back are absolute in the
     reference's own spec.  Whatever that does to the picture at odd scales, the culled nearest hit
     must still equal the brute-force (oracle) one bit for bit."""
     sc = _scaled_scene(name, factor, 128, 96)
-    tr = make_tracer(sc, depth=6)
+    tr = make_tracer(sc, depth=6, ordering=ordering)
     tr.set_image(None); tr.render(1, 3)
     want, live = orc.render(sc, oracle_config(6), 1, 3)
     st = tr.stats()

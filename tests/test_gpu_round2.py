@@ -183,3 +183,46 @@ def test_depth_64_and_rays_that_all_miss(pt, ordering):
     st = tr.stats()
     assert st.live[0] == 3 * 37 * 5 and st.live[1] == 0 and not tr.image().any()
     tr.close()
+
+
+def _stacked_scene(w, h):
+    """60 primitives lined up on the view axis (48 thin slabs, 12 concentric spheres) inside random256's room: nearly every
+    ray has far more than 8 culling candidates."""
+    base = orc.load_golden_scene("random256").with_resolution(w, h)
+    cam = base.camera
+    p = np.array([cam.position[k] for k in range(3)], np.float64)
+    v = np.array([cam.view[k] for k in range(3)], np.float64)
+    v /= np.linalg.norm(v)
+    geoms = list(base.geoms[:6])
+    xf, inv = np.zeros(16, np.float32), np.zeros(16, np.float32)
+
+    def add(kind, centre, scale, rot, mat):
+        orc.lib().orc_build_transform(orc.vec3(*centre), orc.vec3(*rot), orc.vec3(*scale), orc.fptr(xf), orc.fptr(inv))
+        g = orc.Geom()
+        g.type, g.materialid = kind, mat
+        for k in range(16):
+            g.transform[k] = float(xf[k]); g.inverseTransform[k] = float(inv[k])
+        geoms.append(g)
+
+    for k in range(48):
+        add(1, p + v * (2.5 + 0.2 * k), (3.0 - 0.04 * k, 3.0 - 0.04 * k, 0.03), (0.0, 0.0, 7.0 * k), (6, 6, 3, 6, 1 + k % 5)[k % 5])
+    for k in range(12):
+        add(0, p + v * 7.0, (0.6 + 0.45 * k,) * 3, (0.0, 0.0, 0.0), (6, 6, 4)[k % 3])
+    return orc.Scene(geoms, base.materials, cam)
+
+
+@pytest.mark.parametrize("kw", [dict(ordering=0), dict(ordering=1), dict(ordering=1, streams=2, batch=2)])
+def test_many_primitive_kernels_when_the_candidate_list_overflows(pt, kw):
+    """The many-primitive kernels keep at most 8 candidates per ray in registers; a ray with more takes the reference's
+    brute-force loop.  Here nearly every ray does."""
+    sc = _stacked_scene(128, 96)
+    assert sc.G == 66
+    depth, iters = 6, 2
+    tr = make_tracer(sc, depth=depth, **kw)
+    tr.set_image(None)
+    tr.render(1, iters)
+    want, live = orc.render(sc, oracle_config(depth), 1, iters)
+    st = tr.stats()
+    assert [st.live[k] for k in range(depth + 1)] == [int(v) for v in live]
+    assert np.array_equal(tr.image(), want)
+    tr.close()
