@@ -1270,6 +1270,38 @@ __global__ __launch_bounds__(kBlock) void k_fold(FoldArgs a) {
     a.image[p] = r; a.image[p + 1] = g; a.image[p + 2] = b;
 }
 
+// The same fold on 16-byte vectors (frames whose rows are whole float4s: 3 W divisible by 4; every plane and the image
+// are then 16-byte aligned row by row): four consecutive floats of a row per thread, the slots still added one after the
+// other in iteration order -- element by element the very additions of k_fold, so the image is bit-identical.
+__global__ __launch_bounds__(kBlock) void k_fold4(FoldArgs a) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;           // float4 index within the owned rows
+    const uint32_t rowv = (uint32_t)a.W * 3u / 4u;                         // float4s per row
+    if (gid >= (a.n_own / (uint32_t)a.W) * rowv) return;
+    const uint32_t lr = gid / rowv, j = gid - lr * rowv;
+    float4 *ip = reinterpret_cast<float4 *>(a.image + (size_t)(lr * (uint32_t)a.row_stride + (uint32_t)a.row_offset) * (uint32_t)a.W * 3) + j;
+    float4 acc = *ip;
+    float4 *q = reinterpret_cast<float4 *>(a.planes) + gid;
+    const size_t stride4 = a.plane_stride / 4;
+    const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint32_t s = 0;
+    for (; s + 4u <= a.batch; s += 4u) {                                   // four independent loads in flight, added in order
+        const float4 v0 = q[0], v1 = q[stride4], v2 = q[2 * stride4], v3 = q[3 * stride4];
+        q[0] = zero; q[stride4] = zero; q[2 * stride4] = zero; q[3 * stride4] = zero;
+        acc.x = acc.x + v0.x; acc.y = acc.y + v0.y; acc.z = acc.z + v0.z; acc.w = acc.w + v0.w;
+        acc.x = acc.x + v1.x; acc.y = acc.y + v1.y; acc.z = acc.z + v1.z; acc.w = acc.w + v1.w;
+        acc.x = acc.x + v2.x; acc.y = acc.y + v2.y; acc.z = acc.z + v2.z; acc.w = acc.w + v2.w;
+        acc.x = acc.x + v3.x; acc.y = acc.y + v3.y; acc.z = acc.z + v3.z; acc.w = acc.w + v3.w;
+        q += 4 * stride4;
+    }
+    for (; s < a.batch; ++s) {
+        const float4 v = *q;
+        *q = zero;
+        acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w;
+        q += stride4;
+    }
+    *ip = acc;
+}
+
 // ------------------------------------------------------------------ flat (reference) ---
 struct FlatArgs {
     CamRec cam;
@@ -1387,6 +1419,7 @@ struct pt_context {
     bool seg_mode = true;            // wave-autonomous segmented compaction (cfg.compaction == 0)
     bool cull = true;                // AABB candidate culling in front of the exact tests (cfg.culling == 0)
     bool queue = false;              // typed work-queue kernel (cfg.ordering == 1; LDS geometry, G <= 32, no merging)
+    bool flat_pool = false;          //   PT_FLAT_POOL=1 (read at upload): 64-bit flat addressing of the pool even below 4 GiB (A/B switch)
     bool queue_mesh = false;         //   its variant with mesh traversal (scene has MESH primitives with triangles)
     FaceFrame *d_frames = nullptr;   // [G][3] shading frames of the box primitives (k_bounce_q)
     CullRec *d_cull = nullptr;       // bounds for its culling pass, cubes first
@@ -1788,7 +1821,7 @@ int enqueue_iterations(pt_context *c, uint32_t iteration, uint32_t batch, int st
         a.merge = c->lvl_slots[b + 1] != c->lvl_slots[b] ? 1u : 0u;
         a.bounce = b; a.iteration = iteration; a.n_own = c->n_own; a.cam = c->cam; a.bank = c->bank;
         a.pix_mask = c->pix_mask;
-        { const uint64_t pb = (uint64_t)c->cap * kFields * sizeof(float); a.pool_bytes = (c->queue && pb < (1ull << 32) && !getenv("PT_FLAT_POOL")) ? (uint32_t)pb : 0u; }      // PT_FLAT_POOL: A/B switch
+        { const uint64_t pb = (uint64_t)c->cap * kFields * sizeof(float); a.pool_bytes = (c->queue && pb < (1ull << 32) && !c->flat_pool) ? (uint32_t)pb : 0u; }
         a.n_rays = n_rays; a.batch = batch; a.planes = c->d_planes; a.plane_stride = (size_t)c->n_own * 3;
         a.lights = c->d_lights; a.nlights = c->nlights;
         a.nbc = c->nbc; a.nsc = c->nsc; a.cluster_bytes = c->wide ? c->cluster_bytes : 0u;
@@ -1801,7 +1834,14 @@ int enqueue_iterations(pt_context *c, uint32_t iteration, uint32_t batch, int st
         FoldArgs f;
         f.image = c->image; f.planes = c->d_planes; f.plane_stride = (size_t)c->n_own * 3;
         f.batch = batch; f.n_own = c->n_own; f.W = c->W; f.row_offset = c->cfg.row_offset; f.row_stride = c->cfg.row_stride;
-        hipLaunchKernelGGL(k_fold, dim3((c->n_own + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, f);
+        // rows of whole float4s (and a 16-byte aligned image): the vector fold
+        const bool vec = ((uint32_t)c->W * 3u) % 4u == 0u && (reinterpret_cast<uintptr_t>(c->image) & 15u) == 0u && (f.plane_stride % 4u) == 0u;
+        if (vec) {
+            const uint32_t n4 = (c->n_own / (uint32_t)c->W) * ((uint32_t)c->W * 3u / 4u);
+            hipLaunchKernelGGL(k_fold4, dim3((n4 + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, f);
+        } else {
+            hipLaunchKernelGGL(k_fold, dim3((c->n_own + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, f);
+        }
         HIPCHK(hipGetLastError());
     }
     for (int b = 0; b < nb && !c->seg_mode; ++b) {
@@ -2016,6 +2056,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     c->cull = (c->cfg.culling == 0) && c->seg_mode;
     c->queue = c->cull && c->cfg.ordering == 1 && c->cfg.geometry_path == 0 && G <= 32 && c->cfg.mode == 0 && c->cfg.merge_floor <= 0;
     c->queue_mesh = false;
+    c->flat_pool = getenv("PT_FLAT_POOL") != nullptr;
     c->geom_lds = (c->cfg.geometry_path == 0);
     if (have_mesh) {
         // meshes: stable kernels and the typed work queues (where they share the spheres' stack)

@@ -226,3 +226,18 @@ def test_many_primitive_kernels_when_the_candidate_list_overflows(pt, kw):
     assert [st.live[k] for k in range(depth + 1)] == [int(v) for v in live]
     assert np.array_equal(tr.image(), want)
     tr.close()
+
+
+@pytest.mark.parametrize("w,h", [(126, 50), (127, 33), (128, 40)])
+def test_fold_of_batched_iterations_at_widths_with_and_without_whole_float4_rows(pt, w, h):
+    """k_fold4 takes frames whose rows are whole 16-byte vectors (3 W divisible by 4), k_fold the others: same additions in
+    the same order, image bit-identical to the oracle's one-iteration-after-the-other accumulation."""
+    sc = orc.load_golden_scene("cornell_mirror").with_resolution(w, h)
+    for kw in (dict(batch=5), dict(batch=4, streams=2, ordering=1), dict(batch=7, ordering=1, row_offset=1, row_stride=3)):
+        tr = make_tracer(sc, depth=5, **kw)
+        tr.set_image(None)
+        tr.render(1, 9)
+        okw = {k: v for k, v in kw.items() if k in ("row_offset", "row_stride")}
+        want, _ = orc.render(sc, oracle_config(5, **okw), 1, 9)
+        assert np.array_equal(tr.image(), want), (w, h, kw)
+        tr.close()
