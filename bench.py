@@ -12,9 +12,12 @@ Workload at every N (BASELINE configs[2], the configuration the metric is quoted
 scenes/cornell_mirror.txt = Cornell box, 1920x1080, 8 bounces, diffuse + perfect specular, stream
 compaction on.  Inputs (scene tables, accumulator) are resident in HBM before the timed region.
 
-Multi-GPU: the frame's rows are interleaved over the ranks (row y -> rank y % N); each rank keeps
-a full-frame accumulator (zeros outside its rows) and ONE RCCL reduce(sum) to rank 0 ends the
-timed region -> "scaling": "strong" (total work fixed).
+Multi-GPU: the frame's rows are interleaved over the ranks (row y -> rank y % N) -> "scaling": "strong" (total work
+fixed).  The timed region is exactly the K steps on every rank (barrier + synchronize on both sides, max over ranks).
+The frame exchange (owned rows gathered on rank 0, or a full-frame RCCL reduce) happens once per FRAME -- once per the
+scene's ITERATIONS (1000 here), not once per K-step pass: it is timed on its own, bracketed the same way, right after
+the passes, reported as "exchange", and charged to `value` at its true share (t_K + t_exchange * K / ITERATIONS);
+"value_if_exchanged_every_pass" is the figure with one exchange per K steps.
 
 metric value = W*H*steps*depth / seconds / 1e6  ("rays launched x bounces / s", BASELINE.json).
 """
@@ -277,8 +280,15 @@ def main():
         exchange(accum.clone())                # RCCL communicator setup outside the timed region
     torch.cuda.synchronize()
 
+    def max_over_ranks(dt):
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=("cuda:%d" % device) if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
     def timed_pass(first, with_events):
-        """exactly K steps + the frame reduce, bracketed by barrier + synchronize; max over ranks"""
+        """exactly K steps, bracketed by barrier + synchronize; max over ranks"""
         accum.zero_()
         tracer.reset_stats()
         tracer.set_profiling(with_events)
@@ -287,19 +297,22 @@ def main():
         t0 = time.perf_counter()
         tracer.render(first, args.steps)
         tracer.sync()
-        if world > 1:
-            if backend == "nccl":
-                exchange(accum)
-            else:                               # CPU rehearsal of the N>1 path (gloo)
-                exchange(accum.cpu())
         torch.cuda.synchronize()
         barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=("cuda:%d" % device) if backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
+        return max_over_ranks(time.perf_counter() - t0)
+
+    def timed_exchange():
+        """the per-frame exchange of the accumulator just rendered, bracketed the same way; max over ranks"""
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if backend == "nccl":
+            exchange(accum)
+        else:                                   # CPU rehearsal of the N>1 path (gloo)
+            exchange(accum.cpu())
+        torch.cuda.synchronize()
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0)
 
     # 0) untimed passes of the SAME K-step shape until the pass time has settled (the W warm-up steps above form a
     #    differently sized launch group, and a cold chip ramps its clock over the first tens of milliseconds: seven
@@ -322,6 +335,10 @@ def main():
     order = sorted(range(R), key=lambda k: passes[k])
     elapsed = passes[order[R // 2]] if R % 2 else 0.5 * (passes[order[R // 2 - 1]] + passes[order[R // 2]])
     raw = tracer.stats()                          # counters of the last pass: every pass renders the same iterations
+    # N > 1: the frame exchange, once per frame (see the module docstring); three measurements, the median counts
+    exchange_s = sorted(timed_exchange() for _ in range(3))[1] if world > 1 else 0.0
+    frame_iterations = max(int(sf.iterations), args.steps)
+    elapsed_frame_share = elapsed + exchange_s * args.steps / frame_iterations
     # 2) the same K steps once more with every launch bracketed by HIP events on the render stream: per-launch
     #    durations (what rocprofv3 --kernel-trace reports).  NOT used for `value` or `roofline.frac`.
     elapsed_events = None
@@ -332,13 +349,18 @@ def main():
     import types
     stats = types.SimpleNamespace(live=[int(raw.live[k]) for k in range(65)], emitted=int(raw.emitted), iterations=int(raw.iterations),
                                   bounce_launches=int(raw.bounce_launches))
+    if world > 1:                                 # whole-job counters: the live rays / emitter hits of every rank's rows
+        t = torch.tensor(stats.live + [stats.emitted, stats.bounce_launches], dtype=torch.int64, device=("cuda:%d" % device) if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t = [int(v) for v in t.tolist()]
+        stats.live, stats.emitted, stats.bounce_launches = t[:65], t[65], t[66]
     nbytes, design_bytes, live = algorithmic_bytes(stats, depth, fused_generate=(args.compaction == 0))
     result = None
     if rank == 0:
-        value = W * H * args.steps * depth / elapsed / 1e6
+        value = W * H * args.steps * depth / elapsed_frame_share / 1e6
         launches = max(1, int(stats.bounce_launches))
         # roofline on the SAME pass as `value`: SURVEY.md 8(d)'s algorithmic bytes of the K steps / that pass's wall time
-        achieved = nbytes / elapsed / 1e9
+        achieved = nbytes / elapsed_frame_share / 1e9
         traffic = None
         valu = None
         provenance = None
@@ -390,25 +412,36 @@ def main():
                                  "achieved": round(design_bytes / elapsed / 1e9, 1),
                                  "frac": round(design_bytes / elapsed / 1e9 / HBM_PEAK_GBS, 4),
                                  "note": "bytes this implementation actually has to move (fused generation, no write-back at the last bounce, accumulator touched by emitter hits only)"},
-                "launches": launches, "rank0_share_of_frame": round(1.0 / world, 4), "kernel_events": kernel_events, "valu_issue": valu}
+                "launches": launches, "counters": "live rays, emitter hits and launches summed over all %d rank(s)" % world, "kernel_events": kernel_events, "valu_issue": valu}
         live_per_step = sum(live[:depth]) / max(1, int(stats.iterations))
         result = {
             "metric": "Mray/s (rays launched x bounces / s) at 1080p, 8 bounces" if args.workload in ("c3", "c4") else "Mray/s (rays launched x bounces / s)",
             "value": round(value, 1), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": round(elapsed_frame_share / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "repeats": R, "value_is": "median of %d identical K-step passes" % R,
-            "value_min": round(W * H * args.steps * depth / max(passes) / 1e6, 1), "value_max": round(W * H * args.steps * depth / min(passes) / 1e6, 1),
+            "value_min": round(W * H * args.steps * depth / (max(passes) + elapsed_frame_share - elapsed) / 1e6, 1),
+            "value_max": round(W * H * args.steps * depth / (min(passes) + elapsed_frame_share - elapsed) / 1e6, 1),
             "spread": round((max(passes) - min(passes)) / elapsed, 4), "passes_ms": [round(p * 1e3, 4) for p in passes],
-            "live_Mray_bounces_per_s": round(live_per_step * args.steps / elapsed / 1e6, 1),
+            "live_Mray_bounces_per_s": round(live_per_step * args.steps / elapsed_frame_share / 1e6, 1),
             "config": {"workload": desc, "scene": scene_path, "resolution": [W, H], "bounces": depth,
-                       "rays_per_step": W * H, "sharding": "rows interleaved over %d GPU(s), 1 RCCL %s per frame" % (world, "gather of the owned rows" if args.exchange == "gather" else "reduce"),
+                       "rays_per_step": W * H, "sharding": "rows interleaved over %d GPU(s), 1 RCCL %s per frame (timed separately: see exchange)" % (world, "gather of the owned rows" if args.exchange == "gather" else "reduce"),
                        "live_ray_bounces_per_step": round(live_per_step),
                        "compaction": ("segmented, wave-autonomous; " + {0: "stable order (ordering=0)", 1: "typed work queues (ordering=1)"}.get(args.ordering, "stable order")) if args.compaction == 0 else "global look-back scan",
                        "direct_light": bool(args.direct_light), "streams_per_gpu": S,
                        "warmup_passes": "W steps + %d untimed K-step passes (same launch-group shape as the timed passes; until three in a row agree to 1 %%)" % warm_passes},
             "roofline": roof,
         }
+        if world > 1:
+            result["exchange"] = {
+                "kind": "gather of the owned rows on rank 0" if args.exchange == "gather" else "full-frame reduce(sum) to rank 0",
+                "backend": "RCCL over xGMI" if backend == "nccl" else backend + " (CPU rehearsal)",
+                "ms": round(exchange_s * 1e3, 4), "measured": "median of 3, barrier + synchronize on both sides, max over ranks, right after the timed passes",
+                "bytes_received_by_rank0": int(W * H * 12 * (world - 1) / world) if args.exchange == "gather" else W * H * 12,
+                "once_per": "frame = %d iterations (the scene's ITERATIONS)" % frame_iterations,
+                "share_charged_to_value_ms": round(exchange_s * args.steps / frame_iterations * 1e3, 6),
+                "k_steps_only_ms": round(elapsed * 1e3, 4),
+                "value_if_exchanged_every_pass": round(W * H * args.steps * depth / (elapsed + exchange_s) / 1e6, 1)}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(scene_path, depth, options=options)
         print(json.dumps(result), flush=True)

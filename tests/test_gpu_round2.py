@@ -128,6 +128,11 @@ def test_bench_two_ranks_started_plainly_gloo_rehearsal(pt):
     assert res["n_gpus"] == 2 and res["steps"] == 4 and res["value"] > 0 and res["scaling"] == "strong"
     # self-consistent line: frac (4 decimals) = algorithmic bytes per step / ms_per_step / 8 TB/s
     assert res["roofline"]["frac"] == pytest.approx(res["roofline"]["algorithmic_bytes_per_step"] / (res["ms_per_step"] * 1e-3) / 8e12, abs=1e-4)
+    # whole-job counters (both ranks' rows: bounce 0 alone has W*H live rays), and the per-frame exchange timed on its own
+    assert res["config"]["live_ray_bounces_per_step"] >= 640 * 360
+    ex = res["exchange"]
+    assert ex["ms"] > 0 and ex["k_steps_only_ms"] > 0 and ex["value_if_exchanged_every_pass"] < res["value"]
+    assert res["ms_per_step"] * 4 == pytest.approx(ex["k_steps_only_ms"] + ex["share_charged_to_value_ms"], rel=1e-3)
 
 
 def _subset_scene(name, keep, w, h):
