@@ -1270,38 +1270,6 @@ __global__ __launch_bounds__(kBlock) void k_fold(FoldArgs a) {
     a.image[p] = r; a.image[p + 1] = g; a.image[p + 2] = b;
 }
 
-// The same fold on 16-byte vectors (frames whose rows are whole float4s: 3 W divisible by 4; every plane and the image
-// are then 16-byte aligned row by row): four consecutive floats of a row per thread, the slots still added one after the
-// other in iteration order -- element by element the very additions of k_fold, so the image is bit-identical.
-__global__ __launch_bounds__(kBlock) void k_fold4(FoldArgs a) {
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;           // float4 index within the owned rows
-    const uint32_t rowv = (uint32_t)a.W * 3u / 4u;                         // float4s per row
-    if (gid >= (a.n_own / (uint32_t)a.W) * rowv) return;
-    const uint32_t lr = gid / rowv, j = gid - lr * rowv;
-    float4 *ip = reinterpret_cast<float4 *>(a.image + (size_t)(lr * (uint32_t)a.row_stride + (uint32_t)a.row_offset) * (uint32_t)a.W * 3) + j;
-    float4 acc = *ip;
-    float4 *q = reinterpret_cast<float4 *>(a.planes) + gid;
-    const size_t stride4 = a.plane_stride / 4;
-    const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    uint32_t s = 0;
-    for (; s + 4u <= a.batch; s += 4u) {                                   // four independent loads in flight, added in order
-        const float4 v0 = q[0], v1 = q[stride4], v2 = q[2 * stride4], v3 = q[3 * stride4];
-        q[0] = zero; q[stride4] = zero; q[2 * stride4] = zero; q[3 * stride4] = zero;
-        acc.x = acc.x + v0.x; acc.y = acc.y + v0.y; acc.z = acc.z + v0.z; acc.w = acc.w + v0.w;
-        acc.x = acc.x + v1.x; acc.y = acc.y + v1.y; acc.z = acc.z + v1.z; acc.w = acc.w + v1.w;
-        acc.x = acc.x + v2.x; acc.y = acc.y + v2.y; acc.z = acc.z + v2.z; acc.w = acc.w + v2.w;
-        acc.x = acc.x + v3.x; acc.y = acc.y + v3.y; acc.z = acc.z + v3.z; acc.w = acc.w + v3.w;
-        q += 4 * stride4;
-    }
-    for (; s < a.batch; ++s) {
-        const float4 v = *q;
-        *q = zero;
-        acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w;
-        q += stride4;
-    }
-    *ip = acc;
-}
-
 // ------------------------------------------------------------------ flat (reference) ---
 struct FlatArgs {
     CamRec cam;
@@ -1834,14 +1802,7 @@ int enqueue_iterations(pt_context *c, uint32_t iteration, uint32_t batch, int st
         FoldArgs f;
         f.image = c->image; f.planes = c->d_planes; f.plane_stride = (size_t)c->n_own * 3;
         f.batch = batch; f.n_own = c->n_own; f.W = c->W; f.row_offset = c->cfg.row_offset; f.row_stride = c->cfg.row_stride;
-        // rows of whole float4s (and a 16-byte aligned image): the vector fold
-        const bool vec = ((uint32_t)c->W * 3u) % 4u == 0u && (reinterpret_cast<uintptr_t>(c->image) & 15u) == 0u && (f.plane_stride % 4u) == 0u;
-        if (vec) {
-            const uint32_t n4 = (c->n_own / (uint32_t)c->W) * ((uint32_t)c->W * 3u / 4u);
-            hipLaunchKernelGGL(k_fold4, dim3((n4 + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, f);
-        } else {
-            hipLaunchKernelGGL(k_fold, dim3((c->n_own + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, f);
-        }
+        hipLaunchKernelGGL(k_fold, dim3((c->n_own + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, f);
         HIPCHK(hipGetLastError());
     }
     for (int b = 0; b < nb && !c->seg_mode; ++b) {

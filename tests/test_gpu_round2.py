@@ -234,9 +234,9 @@ def test_many_primitive_kernels_when_the_candidate_list_overflows(pt, kw):
 
 
 @pytest.mark.parametrize("w,h", [(126, 50), (127, 33), (128, 40)])
-def test_fold_of_batched_iterations_at_widths_with_and_without_whole_float4_rows(pt, w, h):
-    """k_fold4 takes frames whose rows are whole 16-byte vectors (3 W divisible by 4), k_fold the others: same additions in
-    the same order, image bit-identical to the oracle's one-iteration-after-the-other accumulation."""
+def test_fold_of_batched_iterations_at_odd_widths(pt, w, h):
+    """Batched iterations at frame widths that are no multiple of anything: the per-slot planes hold the owned pixels only,
+    the fold adds them in iteration order -- image bit-identical to the oracle's one-iteration-after-the-other accumulation."""
     sc = orc.load_golden_scene("cornell_mirror").with_resolution(w, h)
     for kw in (dict(batch=5), dict(batch=4, streams=2, ordering=1), dict(batch=7, ordering=1, row_offset=1, row_stride=3)):
         tr = make_tracer(sc, depth=5, **kw)
