@@ -393,7 +393,7 @@ __device__ __forceinline__ int nearest_hit_wide(const GeomRec *lg, const GeomRec
 
 // Dynamic LDS layout (all scratch lives in the dynamic region so that its base stays 16-byte
 // aligned): [0,64) control words | material table | geometry table (LDS path) | ray stage.
-constexpr uint32_t kCtrlBytes = 64;
+constexpr uint32_t kCtrlBytes = 128;         // 32 control words ([0..1] block sums, [2..17] the queue kernel's merged drain)
 
 __device__ __forceinline__ void stage_tables(char *smem_base, const GeomRec *geoms, int G, const MatRec *mats, int M,
                                              bool geoms_in_lds, GeomRec *&lg, MatRec *&lm, uint32_t extra_bytes = 0u) {
@@ -862,6 +862,9 @@ __global__ __launch_bounds__(kBlock, (NEE || WIDE) ? 4 : PT_SEG_WAVES) void k_bo
 constexpr uint32_t kQCap = PT_Q_CAP;
 constexpr uint32_t kQFields = 9;         // ox oy oz dx dy dz idx|pixelword mask next
 
+#ifndef PT_Q_MERGED_DRAIN
+#define PT_Q_MERGED_DRAIN 1              // the four waves of a block pool their last, partly filled stacks (0: every wave drains its own)
+#endif
 #ifndef PT_Q_WAVES
 #define PT_Q_WAVES 6
 #endif
@@ -979,13 +982,134 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : PT_Q_WAVES) void k_bounce_q(SegA
     uint32_t nbox = 0u, nsph = 0u;
     const float kInf = 100000000000000000.0f;
 
+    // One TEST group: `valid` lanes hold a queue record at `r` (per lane), all of the type `isb` says.  Pops nothing and
+    // writes nothing but the accumulator: returns whether the lane's ray lives on, and that ray.
+    auto test_group = [&](const bool isb, const bool valid, const float *r, f3 &o, f3 &d, f3 &thr, uint32_t &pv) -> bool {
+        o = mk(0, 0, 0); d = mk(0, 0, 1); thr = mk(0, 0, 0);
+        pv = 0u;
+        uint32_t idx = 0u, mask = 0u;
+        int j = 0;
+        if (valid) {
+            o = mk(r[0 * kQCap], r[1 * kQCap], r[2 * kQCap]);
+            d = mk(r[3 * kQCap], r[4 * kQCap], r[5 * kQCap]);
+            idx = __float_as_uint(r[6 * kQCap]);
+            mask = __float_as_uint(r[7 * kQCap]);
+            j = (int)__float_as_uint(r[8 * kQCap]);
+            // throughput + pixel word of the ray: requested now, used after the test (nearly every tested ray is a hit)
+            if (GEN) { pv = idx; thr = mk(1.0f, 1.0f, 1.0f); }
+            else {
+                __builtin_assume(idx < (1u << 29));
+                thr = mk(ldf(6, idx), ldf(7, idx), ldf(8, idx));
+                pv = __float_as_uint(ldf(9, idx));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        PT_MARK("exact_begin");
+        // One exact test per popped ray: the queue's type for every lane (jb / jm are per lane only for meshes, which
+        // share the spheres' stack).  Nearest-hit update of the reference loop: first strictly nearer wins, ties to the
+        // lower index -- trivial for the first candidate.
+        float best;
+        int hit, face = -1;
+        f3 P = mk(0, 0, 0), N = mk(0, 0, 0);
+        {
+            const GeomRec *gr = lg + j;                               // per-lane gather from the LDS table
+            float depth = -1.0f;
+            const bool jm = MESH && ((meshbits >> j) & 1u);
+            if (isb) { if (valid) depth = box_test_face(gr->inv, gr->xf, gr->inside_hits, o, d, P, face); }
+            else {
+                if (!MESH || __any(valid && !jm)) { if (valid && !jm) depth = sphere_test(gr->inv, gr->xf, o, d, P, N); }
+                if (MESH) { if (__any(valid && jm)) { if (valid && jm) depth = mesh_test(gr, o, d, P, N); } }
+            }
+            const bool wins = valid && depth > -PT_EPSILON && depth < kInf;
+            best = wins ? depth : kInf;
+            hit = wins ? j : -1;
+        }
+        // The rare rays (0.04 % in the Cornell box) with rivals: candidates entered farther than the best hit are dropped,
+        // the nearest of the rest is tested on the spot, until no lane has one left.
+        if (__any(valid && mask != 0u)) {
+            bool active = valid;
+            for (;;) {
+                int next_j = -1;
+                if (active && mask != 0u) {
+                    const CullRay cr = make_cull_ray(o, d);
+                    float nt = 3.0e38f;
+                    uint32_t m = mask;
+                    while (m) {
+                        const int jj = __builtin_ctz(m);
+                        m &= m - 1u;
+                        const GeomRec *gb = lg + jj;
+                        float tn;
+                        if ((aabbbits >> jj) & 1u) (void)cull_box(gb->bmin, gb->bmax, cr, tn);
+                        else (void)cull_sphere(gb->bmin, gb->bmax, cr, tn);
+                        if (hit >= 0 && tn - gb->slack > best) { mask &= ~(1u << jj); continue; }
+                        if (tn < nt) { nt = tn; next_j = jj; }
+                    }
+                }
+                active = next_j >= 0;
+                if (!__any(active)) break;
+                if (active) { j = next_j; mask &= ~(1u << next_j); }
+                const bool jb = (boxbits >> j) & 1u;
+                const bool jm = MESH && ((meshbits >> j) & 1u);
+                const GeomRec *gr = lg + j;
+                f3 p = mk(0, 0, 0), nn = mk(0, 0, 0);
+                int fc = -1;
+                float depth = -1.0f;
+                if (__any(active && jb)) { if (active && jb) depth = box_test_face(gr->inv, gr->xf, gr->inside_hits, o, d, p, fc); }
+                if (__any(active && !jb && !jm)) { if (active && !jb && !jm) depth = sphere_test(gr->inv, gr->xf, o, d, p, nn); }
+                if (MESH) { if (__any(active && jm)) { if (active && jm) depth = mesh_test(gr, o, d, p, nn); } }
+                const bool wins = active && depth > -PT_EPSILON && (depth < best || (depth == best && j < hit));
+                if (wins) { best = depth; hit = j; P = p; N = nn; face = fc; }
+            }
+        }
+        PT_MARK("exact_end");
+        const bool shade = hit >= 0;
+#ifdef PT_CULL_STATS
+        qstat(isb ? 10 : 12, 1ull); qstat(isb ? 11 : 13, (unsigned long long)__popcll(__ballot(valid)));
+        qstat(14, (unsigned long long)__popcll(__ballot(shade)));
+#endif
+
+        // -------------------------------------------------------------------- shade the hits
+        PT_MARK("shade_begin");
+        bool alive = false;
+        if (shade) {
+            const uint32_t slot = a.batch > 1u ? pv >> 24 : 0u, pixel = pv & a.pix_mask;
+            const MatRec m = lm[lg[hit].mat];
+            if (LAST && !(m.emittance > 0.0f)) {
+                alive = true;                                         // depth exhausted: alive, contributes 0
+            } else {
+                const uint32_t iteration = a.iteration + slot;
+                uint32_t st = lcg_seed(stream_seed(pixel, iteration, 1u + (uint32_t)a.bounce));
+                st = lcg_next(st); const float u_sel = u01(st);
+                st = lcg_next(st); const float xi1 = u01(st);
+                st = lcg_next(st); const float xi2 = u01(st);
+                f3 L = mk(0.0f, 0.0f, 0.0f);
+                int code = 4;
+                const bool hb = (boxbits >> hit) & 1u;
+                if (__any(hb)) { if (hb) code = scatter_box(m, P, face, lf + 3 * hit, u_sel, xi1, xi2, o, d, thr, L); }
+                if (__any(!hb)) { if (!hb) code = scatter(m, P, N, u_sel, xi1, xi2, o, d, thr, L); }
+                if (code == 3) {
+                    float *px = a.batch > 1u ? a.planes + (size_t)slot * a.plane_stride + (size_t)owned_index(a.cam, pixel) * 3
+                                             : a.image + (size_t)pixel * 3;
+                    (void)unsafeAtomicAdd(px, L.x); (void)unsafeAtomicAdd(px + 1, L.y); (void)unsafeAtomicAdd(px + 2, L.z);
+                    emitted++;
+                }
+                alive = code <= 2;
+            }
+        }
+        return alive;
+    };
+
     for (;;) {
         int act;
         if (nbox >= 64u) act = 1;
         else if (nsph >= 64u) act = 2;
         else if (fresh_left && nbox + nsph <= kQCap - 64u) act = 0;
+#if PT_Q_MERGED_DRAIN
+        else if (!fresh_left) break;                      // input exhausted, both stacks below a full group: the block's merged drain
+#else
         else if (nbox + nsph == 0u) break;
-        else act = nbox >= nsph ? 1 : 2;
+#endif
+        else act = nbox >= nsph ? 1 : 2;                  // no room for a fresh group: the fuller stack pops what it has
 
         if (act == 0) {
             // ---------------------------------------------------------------- FRESH
@@ -1086,118 +1210,10 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : PT_Q_WAVES) void k_bounce_q(SegA
         const bool valid = lane < cnt;
         const uint32_t pos = isb ? (have - cnt + lane) : (kQCap - 1u - (have - cnt + lane));
         if (isb) nbox -= cnt; else nsph -= cnt;
-        f3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(0, 0, 0);
-        uint32_t idx = 0u, mask = 0u, pv = 0u;
-        int j = 0;
+        f3 o, d, thr;
+        uint32_t pv;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (valid) {
-            const float *r = q + pos;
-            o = mk(r[0 * kQCap], r[1 * kQCap], r[2 * kQCap]);
-            d = mk(r[3 * kQCap], r[4 * kQCap], r[5 * kQCap]);
-            idx = __float_as_uint(r[6 * kQCap]);
-            mask = __float_as_uint(r[7 * kQCap]);
-            j = (int)__float_as_uint(r[8 * kQCap]);
-            // throughput + pixel word of the ray: requested now, used after the test (nearly every tested ray is a hit)
-            if (GEN) { pv = idx; thr = mk(1.0f, 1.0f, 1.0f); }
-            else {
-                __builtin_assume(idx < (1u << 29));
-                thr = mk(ldf(6, idx), ldf(7, idx), ldf(8, idx));
-                pv = __float_as_uint(ldf(9, idx));
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        PT_MARK("exact_begin");
-        // One exact test per popped ray: the queue's type for every lane (jb / jm are per lane only for meshes, which
-        // share the spheres' stack).  Nearest-hit update of the reference loop: first strictly nearer wins, ties to the
-        // lower index -- trivial for the first candidate.
-        float best;
-        int hit, face = -1;
-        f3 P = mk(0, 0, 0), N = mk(0, 0, 0);
-        {
-            const GeomRec *gr = lg + j;                               // per-lane gather from the LDS table
-            float depth = -1.0f;
-            const bool jm = MESH && ((meshbits >> j) & 1u);
-            if (isb) { if (valid) depth = box_test_face(gr->inv, gr->xf, gr->inside_hits, o, d, P, face); }
-            else {
-                if (!MESH || __any(valid && !jm)) { if (valid && !jm) depth = sphere_test(gr->inv, gr->xf, o, d, P, N); }
-                if (MESH) { if (__any(valid && jm)) { if (valid && jm) depth = mesh_test(gr, o, d, P, N); } }
-            }
-            const bool wins = valid && depth > -PT_EPSILON && depth < kInf;
-            best = wins ? depth : kInf;
-            hit = wins ? j : -1;
-        }
-        // The rare rays (0.04 % in the Cornell box) with rivals: candidates entered farther than the best hit are dropped,
-        // the nearest of the rest is tested on the spot, until no lane has one left.
-        if (__any(valid && mask != 0u)) {
-            bool active = valid;
-            for (;;) {
-                int next_j = -1;
-                if (active && mask != 0u) {
-                    const CullRay cr = make_cull_ray(o, d);
-                    float nt = 3.0e38f;
-                    uint32_t m = mask;
-                    while (m) {
-                        const int jj = __builtin_ctz(m);
-                        m &= m - 1u;
-                        const GeomRec *gb = lg + jj;
-                        float tn;
-                        if ((aabbbits >> jj) & 1u) (void)cull_box(gb->bmin, gb->bmax, cr, tn);
-                        else (void)cull_sphere(gb->bmin, gb->bmax, cr, tn);
-                        if (hit >= 0 && tn - gb->slack > best) { mask &= ~(1u << jj); continue; }
-                        if (tn < nt) { nt = tn; next_j = jj; }
-                    }
-                }
-                active = next_j >= 0;
-                if (!__any(active)) break;
-                if (active) { j = next_j; mask &= ~(1u << next_j); }
-                const bool jb = (boxbits >> j) & 1u;
-                const bool jm = MESH && ((meshbits >> j) & 1u);
-                const GeomRec *gr = lg + j;
-                f3 p = mk(0, 0, 0), nn = mk(0, 0, 0);
-                int fc = -1;
-                float depth = -1.0f;
-                if (__any(active && jb)) { if (active && jb) depth = box_test_face(gr->inv, gr->xf, gr->inside_hits, o, d, p, fc); }
-                if (__any(active && !jb && !jm)) { if (active && !jb && !jm) depth = sphere_test(gr->inv, gr->xf, o, d, p, nn); }
-                if (MESH) { if (__any(active && jm)) { if (active && jm) depth = mesh_test(gr, o, d, p, nn); } }
-                const bool wins = active && depth > -PT_EPSILON && (depth < best || (depth == best && j < hit));
-                if (wins) { best = depth; hit = j; P = p; N = nn; face = fc; }
-            }
-        }
-        PT_MARK("exact_end");
-        const bool shade = hit >= 0;
-#ifdef PT_CULL_STATS
-        qstat(isb ? 10 : 12, 1ull); qstat(isb ? 11 : 13, (unsigned long long)cnt);
-        qstat(14, (unsigned long long)__popcll(__ballot(shade)));
-#endif
-
-        // -------------------------------------------------------------------- shade the hits
-        PT_MARK("shade_begin");
-        bool alive = false;
-        if (shade) {
-            const uint32_t slot = a.batch > 1u ? pv >> 24 : 0u, pixel = pv & a.pix_mask;
-            const MatRec m = lm[lg[hit].mat];
-            if (LAST && !(m.emittance > 0.0f)) {
-                alive = true;                                         // depth exhausted: alive, contributes 0
-            } else {
-                const uint32_t iteration = a.iteration + slot;
-                uint32_t st = lcg_seed(stream_seed(pixel, iteration, 1u + (uint32_t)a.bounce));
-                st = lcg_next(st); const float u_sel = u01(st);
-                st = lcg_next(st); const float xi1 = u01(st);
-                st = lcg_next(st); const float xi2 = u01(st);
-                f3 L = mk(0.0f, 0.0f, 0.0f);
-                int code = 4;
-                const bool hb = (boxbits >> hit) & 1u;
-                if (__any(hb)) { if (hb) code = scatter_box(m, P, face, lf + 3 * hit, u_sel, xi1, xi2, o, d, thr, L); }
-                if (__any(!hb)) { if (!hb) code = scatter(m, P, N, u_sel, xi1, xi2, o, d, thr, L); }
-                if (code == 3) {
-                    float *px = a.batch > 1u ? a.planes + (size_t)slot * a.plane_stride + (size_t)owned_index(a.cam, pixel) * 3
-                                             : a.image + (size_t)pixel * 3;
-                    (void)unsafeAtomicAdd(px, L.x); (void)unsafeAtomicAdd(px + 1, L.y); (void)unsafeAtomicAdd(px + 2, L.z);
-                    emitted++;
-                }
-                alive = code <= 2;
-            }
-        }
+        const bool alive = test_group(isb, valid, q + pos, o, d, thr, pv);
 
         // -------------------------------------------------------------------- survivors -> the wave's output stream
         PT_MARK("out_begin");
@@ -1225,6 +1241,77 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : PT_Q_WAVES) void k_bounce_q(SegA
         survivors += na;
         PT_MARK("loop_end");
     }
+#if PT_Q_MERGED_DRAIN
+    // -------------------------------------------------------------------- the block's merged drain
+    // Every wave arrives here once, with fewer than 64 records on either stack.  The block's leftovers of one type, taken
+    // in wave order, form ceil(total / 64) groups instead of one partly filled group per wave; the groups go round the
+    // waves.  A survivor is appended to the output stream of the wave that QUEUED the ray (a stream holds exactly the
+    // survivors of its own wave's input, so it can never outgrow its segments): cursors in LDS, advanced by ds_add.
+    {
+        uint32_t *ep = ctrl + 2;                              // [0..3] box counts, [4..7] sphere counts, [8..11] stream fill, [12..15] stream segment
+        if (lane == 0) { ep[wave] = nbox; ep[4u + wave] = nsph; ep[8u + wave] = ofill; ep[12u + wave] = oseg; }
+        __syncthreads();
+        uint32_t cb[kWaves], cs[kWaves], dseg[kWaves];
+        uint32_t tb = 0u, ts = 0u;
+#pragma unroll
+        for (uint32_t w = 0; w < (uint32_t)kWaves; ++w) {
+            cb[w] = __builtin_amdgcn_readfirstlane(ep[w]); cs[w] = __builtin_amdgcn_readfirstlane(ep[4u + w]);
+            dseg[w] = __builtin_amdgcn_readfirstlane(ep[12u + w]);
+            tb += cb[w]; ts += cs[w];
+        }
+        const uint32_t gb = (tb + 63u) >> 6, gs = (ts + 63u) >> 6;
+        const float *qall = reinterpret_cast<const float *>(smem + q_lds_offset(a.G, a.M));
+        for (uint32_t grp = wave; grp < gb + gs; grp += (uint32_t)kWaves) {
+            const bool isb = grp < gb;
+            const uint32_t i = ((isb ? grp : grp - gb) << 6) + lane;
+            const bool valid = i < (isb ? tb : ts);
+            // the wave that queued record i, and the record's place on that wave's stack
+            uint32_t donor = 0u, before = 0u, run = 0u;
+#pragma unroll
+            for (uint32_t w = 0; w + 1u < (uint32_t)kWaves; ++w) {
+                run += isb ? cb[w] : cs[w];
+                if (i >= run) { donor = w + 1u; before = run; }
+            }
+            const uint32_t pos = isb ? (i - before) : (kQCap - 1u - (i - before));
+            f3 o, d, thr;
+            uint32_t pv;
+            const bool alive = test_group(isb, valid, qall + (size_t)donor * kQCap * kQFields + pos, o, d, thr, pv);
+            const u64 ballot = __ballot(alive);
+            if (!LAST && ballot) {
+                uint32_t p = 0u, sg = 0u;
+#pragma unroll
+                for (uint32_t w = 0; w < (uint32_t)kWaves; ++w) {
+                    const u64 bw = __ballot(alive && donor == w);
+                    if (bw) {
+                        uint32_t base = 0u;
+                        if (lane == (uint32_t)__builtin_ctzll(bw)) base = atomicAdd(&ep[8u + w], (uint32_t)__popcll(bw));
+                        base = __builtin_amdgcn_readlane(base, __builtin_ctzll(bw));
+                        if (alive && donor == w) { p = base + wave_rank(bw); sg = dseg[w]; }
+                    }
+                }
+                if (alive) {
+                    if (p >= S) { p -= S; sg += nslots; }
+                    const uint32_t oi = sg * S + p;
+                    __builtin_assume(oi < (1u << 29));
+                    stf(0, oi, o.x); stf(1, oi, o.y); stf(2, oi, o.z);
+                    stf(3, oi, d.x); stf(4, oi, d.y); stf(5, oi, d.z);
+                    stf(6, oi, thr.x); stf(7, oi, thr.y); stf(8, oi, thr.z);
+                    stf(9, oi, __uint_as_float(pv));
+                }
+            }
+            survivors += (uint32_t)__popcll(ballot);
+        }
+        if (!LAST) {
+            __syncthreads();                                  // every group of the block has advanced the cursors
+            ofill = __builtin_amdgcn_readfirstlane(ep[8u + wave]);
+            if (ofill >= S) {                                 // at most one segment boundary: a block's leftovers are below 4 x 126 < 3 S ... per stream below 126 < S
+                if (lane == 0) a.cnt_out[oseg] = S;
+                oseg += nslots;
+                ofill -= S;
+            }
+        }
+    }
+#endif
     // close the output stream: the partly filled segment, then zeros for the wave's unused ones
     if (!LAST && lane == 0) {
         uint32_t sg = oseg, c = ofill;
