@@ -3,7 +3,7 @@
 TAG=$1; VAR=$2; ARGS=$3; N=${4:-3}
 for i in $(seq 1 $N); do
   for v in off on; do
-    if [ $v = on ]; then export $VAR=1; else unset $VAR; fi
+    if [ $v = on ]; then export $VAR=${ON:-1}; else if [ -n "${OFF:-}" ]; then export $VAR=$OFF; else unset $VAR; fi; fi
     timeout -k 10 300 python3 bench.py $ARGS --no-cpu-baseline > gpurun_out/${TAG}_${v}_$i.log 2>&1 || { echo "run failed"; tail -5 gpurun_out/${TAG}_${v}_$i.log; exit 1; }
     python3 - gpurun_out/${TAG}_${v}_$i.log "$VAR=$v" <<'PY'
 import json,sys
