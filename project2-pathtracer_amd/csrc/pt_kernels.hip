@@ -865,6 +865,9 @@ constexpr uint32_t kQFields = 9;         // ox oy oz dx dy dz idx|pixelword mask
 #ifndef PT_Q_MERGED_DRAIN
 #define PT_Q_MERGED_DRAIN 1              // the four waves of a block pool their last, partly filled stacks (0: every wave drains its own)
 #endif
+#ifndef PT_Q_PARK
+#define PT_Q_PARK 1                      // launch constants of the accumulate step live in LDS, not in scalar registers
+#endif
 #ifndef PT_Q_WAVES
 #define PT_Q_WAVES 6
 #endif
@@ -901,6 +904,18 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : PT_Q_WAVES) void k_bounce_q(SegA
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *ctrl = reinterpret_cast<uint32_t *>(smem);   // [0] survivors, [1] emitted (block sums)
     if (threadIdx.x < 2) ctrl[threadIdx.x] = 0u;
+#if PT_Q_PARK
+    // Launch constants of the accumulate step, parked in LDS and read where an emitter is hit: they are needed by a few
+    // lanes of a group, and as kernel arguments they would sit in scalar registers across the whole loop (the kernel
+    // spills ~60 of those into vector lanes, every reload a vector instruction).
+    uint32_t *park = ctrl + 18;                            // [18..31]
+    if (threadIdx.x == 0) {
+        const unsigned long long pl = (unsigned long long)(uintptr_t)(a.batch > 1u ? a.planes : a.image), st = (unsigned long long)a.plane_stride;
+        park[0] = (uint32_t)pl; park[1] = (uint32_t)(pl >> 32); park[2] = (uint32_t)st; park[3] = (uint32_t)(st >> 32);
+        park[4] = (uint32_t)a.cam.W; park[5] = (uint32_t)a.cam.row_offset; park[6] = a.cam.mW; park[7] = a.cam.shW;
+        park[8] = a.cam.mS; park[9] = a.cam.shS;
+    }
+#endif
     GeomRec *lg;
     MatRec *lm;
     // LDS: ctrl | materials | geometry | face frames | cull records | 4 wave-private queue buffers
@@ -926,11 +941,22 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : PT_Q_WAVES) void k_bounce_q(SegA
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in), 0, a.pool_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.pool_bytes, 0x00020000);
     const uint32_t cap4 = (uint32_t)cap * 4u;
+    // the field offset f * cap4 is multiplied out where it is used (one scalar instruction): ten products kept across
+    // the loop for each pool are twenty scalar registers the kernel does not have
+    auto field_off = [&](uint32_t f) -> uint32_t {
+#if PT_Q_PARK
+        uint32_t r;
+        __asm__ volatile("s_mul_i32 %0, %1, %2" : "=s"(r) : "s"(cap4), "s"(f));
+        return r;
+#else
+        return f * cap4;
+#endif
+    };
     auto ldf = [&](uint32_t f, uint32_t idx) -> float {
-        return ub ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in, idx * 4u, f * cap4, 0)) : (a.in + (size_t)f * cap)[idx];
+        return ub ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in, idx * 4u, field_off(f), 0)) : (a.in + (size_t)f * cap)[idx];
     };
     auto stf = [&](uint32_t f, uint32_t idx, float v) {
-        if (ub) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out, idx * 4u, f * cap4, 0);
+        if (ub) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out, idx * 4u, field_off(f), 0);
         else (a.out + (size_t)f * cap)[idx] = v;
     };
     uint32_t emitted = 0u, survivors = 0u;
@@ -973,7 +999,8 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : PT_Q_WAVES) void k_bounce_q(SegA
         if (!GEN && fresh_left && lane < 12u) {
             const uint32_t ray = seg * S + g + (lane & 1u) * 32u;
             __builtin_assume(ray < (1u << 29));
-            if (g + (lane & 1u) * 32u < n) warm = ldf(lane >> 1, ray);
+            if (g + (lane & 1u) * 32u < n)                            // per-lane field: the plain multiply
+                warm = ub ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in, ray * 4u, (lane >> 1) * cap4, 0)) : (a.in + (size_t)(lane >> 1) * cap)[ray];
         }
     };
     warm_up();
@@ -1088,8 +1115,21 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : PT_Q_WAVES) void k_bounce_q(SegA
                 if (__any(hb)) { if (hb) code = scatter_box(m, P, face, lf + 3 * hit, u_sel, xi1, xi2, o, d, thr, L); }
                 if (__any(!hb)) { if (!hb) code = scatter(m, P, N, u_sel, xi1, xi2, o, d, thr, L); }
                 if (code == 3) {
+#if PT_Q_PARK
+                    float *base = reinterpret_cast<float *>((uintptr_t)((unsigned long long)park[0] | ((unsigned long long)park[1] << 32)));
+                    size_t off = (size_t)pixel * 3;
+                    if (a.batch > 1u) {
+                        const uint32_t W = park[4];
+                        const uint32_t y = (uint32_t)(((unsigned long long)pixel * park[6]) >> park[7]);
+                        const uint32_t x = pixel - y * W;
+                        const uint32_t ly = (uint32_t)(((unsigned long long)(y - park[5]) * park[8]) >> park[9]);
+                        off = (size_t)slot * (size_t)((unsigned long long)park[2] | ((unsigned long long)park[3] << 32)) + (size_t)(ly * W + x) * 3;
+                    }
+                    float *px = base + off;
+#else
                     float *px = a.batch > 1u ? a.planes + (size_t)slot * a.plane_stride + (size_t)owned_index(a.cam, pixel) * 3
                                              : a.image + (size_t)pixel * 3;
+#endif
                     (void)unsafeAtomicAdd(px, L.x); (void)unsafeAtomicAdd(px + 1, L.y); (void)unsafeAtomicAdd(px + 2, L.z);
                     emitted++;
                 }
