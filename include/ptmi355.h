@@ -112,7 +112,11 @@ typedef struct {
                                     test of a ray against its nearest candidate; rays wait on wave-private LDS stacks
                                     by candidate type and both stages run on full waves; survivors fill the wave's own
                                     segments densely (fastest; survivors keep their wave, not their segment or order;
-                                    results identical).  Other values behave like 0. */
+                                    results identical).
+                                2 = whole paths on the typed work queues: ONE launch per group; waves draw jobs of camera
+                                    rays from a ticket counter and keep every ray from the camera to its end (queue records
+                                    carry the ray and its bounce level, survivors wait in small per-wave rings per level);
+                                    same conditions as 1, no meshes; results identical.  Other values behave like 0. */
     int   bvh;               /* unused (round-1 experiments, removed); scenes with 33..256 analytic primitives use
                                 two-level cluster culling automatically, meshes carry their own BVH */
     int   direct_light;      /* 1 = next-event estimation: at every diffuse hit one shadow

@@ -393,7 +393,7 @@ __device__ __forceinline__ int nearest_hit_wide(const GeomRec *lg, const GeomRec
 
 // Dynamic LDS layout (all scratch lives in the dynamic region so that its base stays 16-byte
 // aligned): [0,64) control words | material table | geometry table (LDS path) | ray stage.
-constexpr uint32_t kCtrlBytes = 128;         // 32 control words ([0..1] block sums, [2..17] the queue kernel's merged drain)
+constexpr uint32_t kCtrlBytes = 512;         // 128 control words: [0..1] block sums, [2..17] merged drain, [18..31] parked launch constants, [32..96] k_path_q survivors per level
 
 __device__ __forceinline__ void stage_tables(char *smem_base, const GeomRec *geoms, int G, const MatRec *mats, int M,
                                              bool geoms_in_lds, GeomRec *&lg, MatRec *&lm, uint32_t extra_bytes = 0u) {
@@ -1370,6 +1370,341 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : PT_Q_WAVES) void k_bounce_q(SegA
     }
 }
 
+// ------------------------------------------------------------------ whole paths on typed work queues ---
+// ordering = 2: ONE launch per group takes every ray from the camera to its end.  The two stages are those of
+// k_bounce_q, but nothing is per bounce any more:
+//   * a wave draws small jobs of camera rays from a device ticket counter (dynamic balance, one short tail per launch);
+//   * a queue record is the whole ray (origin, direction, throughput, pixel word) + candidate mask, nearest candidate and
+//     its LEVEL (bounce index), so records of different bounces share the two typed stacks and a partly filled stack
+//     never has to be popped before the launch ends;
+//   * survivors of a TEST group go on the wave's own small STACK of rays in global memory (256 slots x 44 B: the ray and
+//     its level), written and read back by the same wave within a few groups -- L2 traffic, 70 MB for the whole chip
+//     instead of two 0.8-GB pools; FRESH takes the top 64 rays of the stack when it holds 64 (depth first: the stack never
+//     holds more than 63 + 2 x 64 rays), else a group of camera rays, else whatever is left.
+// No barrier, no inter-wave traffic, no pool; per-level live counts through one LDS atomic per group.  Results: the same image, live
+// counts and emitter hits as every other kernel (the rays of a bounce are a set, not a sequence).
+#ifndef PT_P_CAP
+#define PT_P_CAP 152
+#endif
+constexpr uint32_t kPCap = PT_P_CAP;
+constexpr uint32_t kPFields = 13;        // ox oy oz dx dy dz tx ty tz pixelword mask candidate level
+constexpr uint32_t kStack = 256;         // rays on a wave's stack (bound: 63 + two pops of 64)
+constexpr uint32_t kSFields = 11;        // ox oy oz dx dy dz tx ty tz pixelword level
+#ifndef PT_P_JOB
+#define PT_P_JOB 512
+#endif
+constexpr uint32_t kJobRays = PT_P_JOB;       // camera rays per ticket
+
+struct PathArgs {
+    float *arena;                    // [waves][kSFields][kStack]
+    uint32_t arena_bytes;            // != 0: below 4 GiB, buffer addressing
+    uint32_t depth;
+    uint32_t *ticket;                // zero before the launch
+    uint32_t *error;
+};
+
+__host__ __device__ inline uint32_t p_cursor_offset(int G, int M) { return q_lds_offset(G, M); }
+__host__ __device__ inline uint32_t p_queue_offset(int G, int M) { return p_cursor_offset(G, M); }
+__host__ __device__ inline uint32_t p_lds_bytes(int G, int M) { return p_queue_offset(G, M) + (uint32_t)kWaves * kPCap * kPFields * 4u; }
+
+__global__ __launch_bounds__(kBlock, 4) void k_path_q(SegArgs a, PathArgs pa, const GeomRec *__restrict__ geoms,
+                                                      const MatRec *__restrict__ mats, QTables qt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t *ctrl = reinterpret_cast<uint32_t *>(smem);   // [1] emitted (block sum), [32..96] survivors per level
+    uint32_t *lsurv = ctrl + 32;
+    if (threadIdx.x < 2) ctrl[threadIdx.x] = 0u;
+    if (threadIdx.x < 65) lsurv[threadIdx.x] = 0u;
+    uint32_t *park = ctrl + 18;
+    if (threadIdx.x == 0) {
+        const unsigned long long pl = (unsigned long long)(uintptr_t)(a.batch > 1u ? a.planes : a.image), st = (unsigned long long)a.plane_stride;
+        park[0] = (uint32_t)pl; park[1] = (uint32_t)(pl >> 32); park[2] = (uint32_t)st; park[3] = (uint32_t)(st >> 32);
+        park[4] = (uint32_t)a.cam.W; park[5] = (uint32_t)a.cam.row_offset; park[6] = a.cam.mW; park[7] = a.cam.shW;
+        park[8] = a.cam.mS; park[9] = a.cam.shS;
+    }
+    GeomRec *lg;
+    MatRec *lm;
+    FaceFrame *lf = reinterpret_cast<FaceFrame *>(smem + q_frames_offset(a.G, a.M));
+    CullRec *lc = reinterpret_cast<CullRec *>(smem + q_cull_offset(a.G, a.M));
+    {
+        uint32_t *fd = reinterpret_cast<uint32_t *>(lf);
+        const uint32_t *fs = reinterpret_cast<const uint32_t *>(qt.frames);
+        for (uint32_t i = threadIdx.x; i < (uint32_t)a.G * 3u * (uint32_t)(sizeof(FaceFrame) / 4); i += blockDim.x) fd[i] = fs[i];
+        uint32_t *cd = reinterpret_cast<uint32_t *>(lc);
+        const uint32_t *cs = reinterpret_cast<const uint32_t *>(qt.cull);
+        for (uint32_t i = threadIdx.x; i < (uint32_t)(qt.nbox + qt.nsph) * (uint32_t)(sizeof(CullRec) / 4); i += blockDim.x) cd[i] = cs[i];
+    }
+    stage_tables(smem, geoms, a.G, mats, a.M, true, lg, lm);        // ends with __syncthreads()
+
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
+    const uint32_t wslot = blockIdx.x * kWaves + wave;
+    const uint32_t D = pa.depth;
+    float *q = reinterpret_cast<float *>(smem + p_queue_offset(a.G, a.M)) + (size_t)wave * kPCap * kPFields;
+    // the wave's stack: field f of slot s at woff + f * kStack + s
+    const uint32_t wave_floats = kSFields * kStack;
+    const bool ub = pa.arena_bytes != 0u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pa.arena, 0, pa.arena_bytes, 0x00020000);
+    const uint32_t woff = wslot * wave_floats;             // in floats (buffer path: arena below 4 GiB)
+    auto ring_ld = [&](uint32_t off, uint32_t f) -> float {         // off = float index of field 0 of the slot
+        return ub ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off * 4u, f * kStack * 4u, 0)) : pa.arena[(size_t)off + f * kStack];
+    };
+    auto ring_st = [&](uint32_t off, uint32_t f, float v) {
+        if (ub) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, off * 4u, f * kStack * 4u, 0);
+        else pa.arena[(size_t)off + f * kStack] = v;
+    };
+
+    uint32_t *bank = a.bank ? a.sync->counts_b : a.sync->counts;
+    if (blockIdx.x == 0 && threadIdx.x < 72) {
+        uint32_t *other = a.bank ? a.sync->counts : a.sync->counts_b;
+        a.sync->totals[threadIdx.x] += other[threadIdx.x];
+        other[threadIdx.x] = 0u;
+        if (threadIdx.x == 0) bank[0] = a.n_rays;
+    }
+    uint32_t boxbits = 0u;
+    for (int j = 0; j < a.G; ++j)
+        if (lg[j].type == 1) boxbits |= 1u << j;
+
+    uint32_t emitted = 0u;
+    uint32_t nbox = 0u, nsph = 0u;
+    uint32_t sp = 0u;                                      // rays on the wave's stack
+    uint32_t jobpos = 0u, jobend = 0u;
+    bool tickets_left = true;
+    uint32_t turns = 0u;
+    const float kInf = 100000000000000000.0f;
+
+    for (;;) {
+        if (++turns > (1u << 24)) { if (lane == 0) *pa.error = 3u; break; }                // never reached; bounds a broken build
+        int act;
+        if (nbox >= 64u) act = 1;
+        else if (nsph >= 64u) act = 2;
+        else if (nbox + nsph <= kPCap - 64u) {
+            if (sp >= 64u) act = 0;
+            else {
+                if (jobpos >= jobend && tickets_left) {                                    // next job of camera rays
+                    uint32_t t = 0u;
+                    if (lane == 0) t = atomicAdd(pa.ticket, 1u);
+                    t = __builtin_amdgcn_readfirstlane(t);
+                    const unsigned long long first = (unsigned long long)t * kJobRays;
+                    if (first >= (unsigned long long)a.n_rays) tickets_left = false;
+                    else { jobpos = (uint32_t)first; jobend = a.n_rays - jobpos < kJobRays ? a.n_rays : jobpos + kJobRays; }
+                }
+                if (jobpos < jobend) act = 3;
+                else if (sp) act = 0;
+                else if (nbox + nsph) act = nbox >= nsph ? 1 : 2;
+                else break;
+            }
+        } else act = nbox >= nsph ? 1 : 2;
+
+        if (act == 0 || act == 3) {
+            // ---------------------------------------------------------------- FRESH
+            f3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(1.0f, 1.0f, 1.0f);
+            uint32_t pv = 0u, level = 0u;
+            bool valid;
+            if (act == 3) {                                                                // camera rays
+                const uint32_t ray = jobpos + lane;
+                valid = ray < jobend;
+                jobpos = jobpos + 64u < jobend ? jobpos + 64u : jobend;
+                if (valid) {
+                    const uint32_t slot = a.batch > 1u ? ray / a.n_own : 0u;
+                    const uint32_t local = ray - slot * a.n_own;
+                    const uint32_t W = (uint32_t)a.cam.W;
+                    const uint32_t lr = local / W, x = local - lr * W;
+                    const uint32_t pixel = (lr * (uint32_t)a.cam.row_stride + (uint32_t)a.cam.row_offset) * W + x;
+                    camera_ray(a.cam, pixel, a.iteration + slot, o, d);
+                    pv = pixel | (slot << 24);
+                }
+            } else {                                                                       // the top of the wave's stack
+                const uint32_t cnt = sp < 64u ? sp : 64u;
+                valid = lane < cnt;
+                sp -= cnt;
+                const uint32_t off = woff + sp + lane;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // the wave's own stack stores have landed (vmcnt 0) ...
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");        // ... before they are read back through the same L1
+                if (valid) {
+                    o = mk(ring_ld(off, 0), ring_ld(off, 1), ring_ld(off, 2));
+                    d = mk(ring_ld(off, 3), ring_ld(off, 4), ring_ld(off, 5));
+                    thr = mk(ring_ld(off, 6), ring_ld(off, 7), ring_ld(off, 8));
+                    pv = __float_as_uint(ring_ld(off, 9));
+                    level = __float_as_uint(ring_ld(off, 10));
+                }
+            }
+            const CullRay cr = make_cull_ray(o, d);
+            float near_t = 3.0e38f;
+            uint32_t mask = 0u, next_j = 0u;
+#pragma unroll 2
+            for (int i = 0; i < qt.nbox; ++i) {
+                const CullRec r = lc[i];
+                float tn;
+                const bool keep = cull_box(r.a, r.b, cr, tn);
+                mask |= keep ? __float_as_uint(r.b[3]) : 0u;
+                const bool nearer = keep && tn < near_t;
+                near_t = nearer ? tn : near_t;
+                next_j = nearer ? __float_as_uint(r.a[3]) : next_j;
+            }
+#pragma unroll 2
+            for (int i = qt.nbox; i < qt.nbox + qt.nsph; ++i) {
+                const CullRec r = lc[i];
+                float tn;
+                const bool keep = cull_sphere(r.a, r.b, cr, tn);
+                mask |= keep ? __float_as_uint(r.b[1]) : 0u;
+                const bool nearer = keep && tn < near_t;
+                near_t = nearer ? tn : near_t;
+                next_j = nearer ? __float_as_uint(r.b[0]) : next_j;
+            }
+            if (!valid) mask = 0u;
+            const bool push = mask != 0u;
+            mask &= ~(1u << next_j);
+            const bool tobox = push && ((boxbits >> next_j) & 1u);
+            const u64 bb = __ballot(tobox), sb = __ballot(push && !tobox);
+            if (bb | sb) {
+                if (push) {
+                    const uint32_t pos = tobox ? nbox + wave_rank(bb) : kPCap - 1u - (nsph + wave_rank(sb));
+                    float *r = q + pos;
+                    r[0 * kPCap] = o.x; r[1 * kPCap] = o.y; r[2 * kPCap] = o.z;
+                    r[3 * kPCap] = d.x; r[4 * kPCap] = d.y; r[5 * kPCap] = d.z;
+                    r[6 * kPCap] = thr.x; r[7 * kPCap] = thr.y; r[8 * kPCap] = thr.z;
+                    r[9 * kPCap] = __uint_as_float(pv);
+                    r[10 * kPCap] = __uint_as_float(mask);
+                    r[11 * kPCap] = __uint_as_float(next_j);
+                    r[12 * kPCap] = __uint_as_float(level);
+                }
+                nbox += (uint32_t)__popcll(bb);
+                nsph += (uint32_t)__popcll(sb);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            continue;
+        }
+
+        // -------------------------------------------------------------------- TEST (one type per group, any levels)
+        const bool isb = act == 1;
+        const uint32_t have = isb ? nbox : nsph;
+        const uint32_t cnt = have < 64u ? have : 64u;
+        const bool valid = lane < cnt;
+        const uint32_t pos = isb ? (have - cnt + lane) : (kPCap - 1u - (have - cnt + lane));
+        if (isb) nbox -= cnt; else nsph -= cnt;
+        f3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(0, 0, 0);
+        uint32_t pv = 0u, mask = 0u, level = 0u;
+        int j = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (valid) {
+            const float *r = q + pos;
+            o = mk(r[0 * kPCap], r[1 * kPCap], r[2 * kPCap]);
+            d = mk(r[3 * kPCap], r[4 * kPCap], r[5 * kPCap]);
+            thr = mk(r[6 * kPCap], r[7 * kPCap], r[8 * kPCap]);
+            pv = __float_as_uint(r[9 * kPCap]);
+            mask = __float_as_uint(r[10 * kPCap]);
+            j = (int)__float_as_uint(r[11 * kPCap]);
+            level = __float_as_uint(r[12 * kPCap]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        float best;
+        int hit, face = -1;
+        f3 P = mk(0, 0, 0), N = mk(0, 0, 0);
+        {
+            const GeomRec *gr = lg + j;
+            float depth = -1.0f;
+            if (isb) { if (valid) depth = box_test_face(gr->inv, gr->xf, gr->inside_hits, o, d, P, face); }
+            else { if (valid) depth = sphere_test(gr->inv, gr->xf, o, d, P, N); }
+            const bool wins = valid && depth > -PT_EPSILON && depth < kInf;
+            best = wins ? depth : kInf;
+            hit = wins ? j : -1;
+        }
+        if (__any(valid && mask != 0u)) {
+            bool active = valid;
+            for (;;) {
+                int next_j = -1;
+                if (active && mask != 0u) {
+                    const CullRay cr = make_cull_ray(o, d);
+                    float nt = 3.0e38f;
+                    uint32_t m = mask;
+                    while (m) {
+                        const int jj = __builtin_ctz(m);
+                        m &= m - 1u;
+                        const GeomRec *gb = lg + jj;
+                        float tn;
+                        if ((boxbits >> jj) & 1u) (void)cull_box(gb->bmin, gb->bmax, cr, tn);
+                        else (void)cull_sphere(gb->bmin, gb->bmax, cr, tn);
+                        if (hit >= 0 && tn - gb->slack > best) { mask &= ~(1u << jj); continue; }
+                        if (tn < nt) { nt = tn; next_j = jj; }
+                    }
+                }
+                active = next_j >= 0;
+                if (!__any(active)) break;
+                if (active) { j = next_j; mask &= ~(1u << next_j); }
+                const bool jb = (boxbits >> j) & 1u;
+                const GeomRec *gr = lg + j;
+                f3 p = mk(0, 0, 0), nn = mk(0, 0, 0);
+                int fc = -1;
+                float depth = -1.0f;
+                if (__any(active && jb)) { if (active && jb) depth = box_test_face(gr->inv, gr->xf, gr->inside_hits, o, d, p, fc); }
+                if (__any(active && !jb)) { if (active && !jb) depth = sphere_test(gr->inv, gr->xf, o, d, p, nn); }
+                const bool wins = active && depth > -PT_EPSILON && (depth < best || (depth == best && j < hit));
+                if (wins) { best = depth; hit = j; P = p; N = nn; face = fc; }
+            }
+        }
+        // shade the hits (the ray's own level is its bounce index)
+        bool alive = false;
+        if (hit >= 0) {
+            const uint32_t slot = a.batch > 1u ? pv >> 24 : 0u, pixel = pv & a.pix_mask;
+            const MatRec m = lm[lg[hit].mat];
+            if (level + 1u >= D && !(m.emittance > 0.0f)) {
+                alive = true;                                         // depth exhausted: alive, contributes 0
+            } else {
+                const uint32_t iteration = a.iteration + slot;
+                uint32_t st = lcg_seed(stream_seed(pixel, iteration, 1u + level));
+                st = lcg_next(st); const float u_sel = u01(st);
+                st = lcg_next(st); const float xi1 = u01(st);
+                st = lcg_next(st); const float xi2 = u01(st);
+                f3 L = mk(0.0f, 0.0f, 0.0f);
+                int code = 4;
+                const bool hb = (boxbits >> hit) & 1u;
+                if (__any(hb)) { if (hb) code = scatter_box(m, P, face, lf + 3 * hit, u_sel, xi1, xi2, o, d, thr, L); }
+                if (__any(!hb)) { if (!hb) code = scatter(m, P, N, u_sel, xi1, xi2, o, d, thr, L); }
+                if (code == 3) {
+                    float *base = reinterpret_cast<float *>((uintptr_t)((unsigned long long)park[0] | ((unsigned long long)park[1] << 32)));
+                    size_t off = (size_t)pixel * 3;
+                    if (a.batch > 1u) {
+                        const uint32_t W = park[4];
+                        const uint32_t y = (uint32_t)(((unsigned long long)pixel * park[6]) >> park[7]);
+                        const uint32_t x = pixel - y * W;
+                        const uint32_t ly = (uint32_t)(((unsigned long long)(y - park[5]) * park[8]) >> park[9]);
+                        off = (size_t)slot * (size_t)((unsigned long long)park[2] | ((unsigned long long)park[3] << 32)) + (size_t)(ly * W + x) * 3;
+                    }
+                    float *px = base + off;
+                    (void)unsafeAtomicAdd(px, L.x); (void)unsafeAtomicAdd(px + 1, L.y); (void)unsafeAtomicAdd(px + 2, L.z);
+                    emitted++;
+                }
+                alive = code <= 2;
+            }
+        }
+        // survivors: counted per level (one LDS atomic for the group); those with bounces left go on the wave's stack
+        if (alive) atomicAdd(&lsurv[level + 1u], 1u);
+        const bool onward = alive && level + 1u < D;
+        const u64 ballot = __ballot(onward);
+        if (ballot) {
+            const uint32_t n = (uint32_t)__popcll(ballot);
+            if (sp + n > kStack) { if (lane == 0) *pa.error = 2u; }        // never: see the bound above
+            else {
+                if (onward) {
+                    const uint32_t off = woff + sp + wave_rank(ballot);
+                    ring_st(off, 0, o.x); ring_st(off, 1, o.y); ring_st(off, 2, o.z);
+                    ring_st(off, 3, d.x); ring_st(off, 4, d.y); ring_st(off, 5, d.z);
+                    ring_st(off, 6, thr.x); ring_st(off, 7, thr.y); ring_st(off, 8, thr.z);
+                    ring_st(off, 9, __uint_as_float(pv));
+                    ring_st(off, 10, __uint_as_float(level + 1u));
+                }
+                sp += n;
+            }
+        }
+    }
+
+    for (int sft = 32; sft > 0; sft >>= 1) emitted += __shfl_down(emitted, sft);
+    if (lane == 0 && emitted) atomicAdd(&ctrl[1], emitted);
+    __syncthreads();
+    if (threadIdx.x == 0 && ctrl[1]) atomicAdd(&a.sync->emitted, (u64)ctrl[1]);
+    if (threadIdx.x >= 1 && threadIdx.x < 65 && lsurv[threadIdx.x]) atomicAdd(&bank[threadIdx.x], lsurv[threadIdx.x]);
+}
+
 // ------------------------------------------------------------------ fold (batched iterations) ---
 // image[p] = (((image[p] + plane_0[p]) + plane_1[p]) + ...) in iteration order -- the same sum, in the
 // same order, as rendering the iterations one after the other -- and clears the planes for the next
@@ -1514,6 +1849,11 @@ struct pt_context {
     bool seg_mode = true;            // wave-autonomous segmented compaction (cfg.compaction == 0)
     bool cull = true;                // AABB candidate culling in front of the exact tests (cfg.culling == 0)
     bool queue = false;              // typed work-queue kernel (cfg.ordering == 1; LDS geometry, G <= 32, no merging)
+    bool pathq = false;              //   cfg.ordering == 2: whole paths in one launch (k_path_q), rings instead of pools
+    float *d_arena = nullptr;        //   [grid_path * kWaves][kSFields][kStack]: the waves' ray stacks
+    size_t arena_bytes = 0;
+    int grid_path = 0;
+    uint32_t lds_path = 0;
     bool flat_pool = false;          //   PT_FLAT_POOL=1 (read at upload): 64-bit flat addressing of the pool even below 4 GiB (A/B switch)
     bool queue_mesh = false;         //   its variant with mesh traversal (scene has MESH primitives with triangles)
     FaceFrame *d_frames = nullptr;   // [G][3] shading frames of the box primitives (k_bounce_q)
@@ -1616,6 +1956,8 @@ void free_scene_buffers(pt_context *c) {
     c->d_frames = nullptr;
     if (c->d_cull) (void)hipFree(c->d_cull);
     c->d_cull = nullptr;
+    if (c->d_arena) (void)hipFree(c->d_arena);
+    c->d_arena = nullptr;
     for (void *b : c->d_mesh_blobs) (void)hipFree(b);
     c->d_mesh_blobs.clear();
     if (c->image == c->image_own) c->image = nullptr;
@@ -1907,6 +2249,36 @@ int enqueue_iterations(pt_context *c, uint32_t iteration, uint32_t batch, int st
     }
     const int nb = stop_after < 0 ? D : stop_after;
     if (fused) c->bank ^= 1u;
+    if (c->pathq && stop_after < 0) {
+        // whole paths: one launch for the group (the per-bounce launches below remain the parity hooks' path)
+        SegArgs a;
+        memset(&a, 0, sizeof a);
+        a.cap = c->cap; a.image = c->image; a.G = c->G; a.M = c->M; a.sync = c->d_sync;
+        a.iteration = iteration; a.n_own = c->n_own; a.cam = c->cam; a.bank = c->bank; a.pix_mask = c->pix_mask;
+        a.n_rays = n_rays; a.batch = batch; a.planes = c->d_planes; a.plane_stride = (size_t)c->n_own * 3;
+        PathArgs pa;
+        pa.arena = c->d_arena; pa.arena_bytes = c->arena_bytes < (1ull << 32) ? (uint32_t)c->arena_bytes : 0u;
+        pa.depth = (uint32_t)D; pa.ticket = &c->d_sync->tickets[0]; pa.error = &c->d_sync->error;
+        QTables qt;
+        qt.frames = c->d_frames; qt.cull = c->d_cull; qt.nbox = c->q_nbox; qt.nsph = c->q_nsph;
+        HIPCHK(hipMemsetAsync(pa.ticket, 0, sizeof(uint32_t), c->stream));
+        {
+            Scoped s(c, 1);
+            hipLaunchKernelGGL(k_path_q, dim3(c->grid_path), dim3(kBlock), c->lds_path, c->stream, a, pa,
+                               (const GeomRec *)c->d_geoms, (const MatRec *)c->d_mats, qt);
+            HIPCHK(hipGetLastError());
+        }
+        if (batch > 1u) {
+            Scoped s(c, 0);
+            FoldArgs f;
+            f.image = c->image; f.planes = c->d_planes; f.plane_stride = (size_t)c->n_own * 3;
+            f.batch = batch; f.n_own = c->n_own; f.W = c->W; f.row_offset = c->cfg.row_offset; f.row_stride = c->cfg.row_stride;
+            hipLaunchKernelGGL(k_fold, dim3((c->n_own + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, f);
+            HIPCHK(hipGetLastError());
+        }
+        c->counts_pending = true;
+        return PT_OK;
+    }
     for (int b = 0; b < nb && c->seg_mode; ++b) {
         SegArgs a;
         a.in = c->pool[b & 1]; a.out = c->pool[(b + 1) & 1]; a.cap = c->cap; a.image = c->image;
@@ -1949,6 +2321,7 @@ int enqueue_iterations(pt_context *c, uint32_t iteration, uint32_t batch, int st
 int check_device_error(pt_context *c) {
     uint32_t err = 0;
     HIPCHK(hipMemcpy(&err, &c->d_sync->error, sizeof err, hipMemcpyDeviceToHost));
+    if (err == 2u || err == 3u) { pth::set_error("whole-path kernel: %s (device state corrupt)", err == 2u ? "a level ring overflowed" : "turn limit reached"); return PT_ERR_HIP; }
     if (err) { pth::set_error("compaction look-back exceeded its spin limit (device sync state corrupt)"); return PT_ERR_HIP; }
     return PT_OK;
 }
@@ -2142,7 +2515,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     }
     c->seg_mode = (c->cfg.compaction == 0);
     c->cull = (c->cfg.culling == 0) && c->seg_mode;
-    c->queue = c->cull && c->cfg.ordering == 1 && c->cfg.geometry_path == 0 && G <= 32 && c->cfg.mode == 0 && c->cfg.merge_floor <= 0;
+    c->queue = c->cull && (c->cfg.ordering == 1 || c->cfg.ordering == 2) && c->cfg.geometry_path == 0 && G <= 32 && c->cfg.mode == 0 && c->cfg.merge_floor <= 0;
     c->queue_mesh = false;
     c->flat_pool = getenv("PT_FLAT_POOL") != nullptr;
     c->geom_lds = (c->cfg.geometry_path == 0);
@@ -2402,6 +2775,17 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         if (cr.empty()) cr.emplace_back();
         HIPCHK(hipMalloc(&c->d_cull, cr.size() * sizeof(CullRec)));
         HIPCHK(hipMemcpy(c->d_cull, cr.data(), cr.size() * sizeof(CullRec), hipMemcpyHostToDevice));
+    }
+    // ordering = 2: whole paths in one launch -- a persistent grid of its own and the waves' level rings
+    c->pathq = c->queue && !c->queue_mesh && c->cfg.ordering == 2 && !c->nee;
+    if (c->pathq) {
+        c->lds_path = p_lds_bytes(G, M);
+        int occ = 0;
+        if (c->cfg.blocks_per_cu > 0) occ = c->cfg.blocks_per_cu;
+        else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(&k_path_q), kBlock, c->lds_path) != hipSuccess || occ < 1) occ = 2;
+        c->grid_path = c->n_cu * occ;
+        c->arena_bytes = (size_t)c->grid_path * kWaves * (size_t)kSFields * kStack * sizeof(float);
+        HIPCHK(hipMalloc(&c->d_arena, c->arena_bytes));
     }
     pth::camera_basis(cam, &c->cfg, &c->cam);
     c->scene_ready = true;

@@ -520,7 +520,7 @@ def test_light_sampling_helpers_bit_exact(pt):
 @pytest.mark.parametrize("scene_name,depth,iters,kw", [
     ("sampleScene", 8, 5, dict()), ("cornell_mirror", 8, 4, dict()), ("cornell_glass_4k", 12, 3, dict()),
     ("cornell_glass_4k", 6, 3, dict(camera_mode=1, antialias=1, aperture=0.25, focal_distance=12.0))])
-@pytest.mark.parametrize("ordering", [1])
+@pytest.mark.parametrize("ordering", [1, 2])
 def test_sparse_work_queue_ordering_is_bit_identical(pt, scene_name, depth, iters, kw, ordering):
     """ordering=1 (typed work queues: one exact test per stage on full waves): same image, same live counts as the
     oracle; the pool holds the same set of rays."""

@@ -15,7 +15,7 @@ from gpu_common import make_tracer, oracle_config, to_product
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("ordering", [0, 1])
+@pytest.mark.parametrize("ordering", [0, 1, 2])
 def test_frame_above_2pow24_pixels_matches_oracle_rows(pt, ordering):
     """4100x4100 = 16.8 Mpx: the pool's pixel word has no room for an iteration slot any more; the
     library renders one iteration per launch with the raw 32-bit pixel index (VERDICT r1 weak #7)."""
@@ -93,7 +93,7 @@ def test_owned_row_exchange_host_and_peer(pt, streams):
 
 
 @pytest.mark.parametrize("kw", [dict(ordering=1, streams=2), dict(ordering=0, streams=2), dict(ordering=1, streams=1),
-                                dict(direct_light=1, streams=2)])
+                                dict(direct_light=1, streams=2), dict(ordering=2, streams=1), dict(ordering=2, streams=2)])
 def test_headline_launch_variant_full_size_against_oracle_rows(pt, kw):
     """What bench.py times (configs[2] at 1920x1080, ordering=1, streams=2, automatic batching over a
     20-iteration launch group) against the oracle on an interleave of rows (VERDICT r1 weak #8)."""
@@ -146,7 +146,7 @@ def _subset_scene(name, keep, w, h):
     ("spheres only (no enclosing room)", [i for i in range(6, 70) if i % 2 == 0][:32]),
     ("one sphere", [6]),
 ])
-@pytest.mark.parametrize("kw", [dict(ordering=1), dict(ordering=1, streams=2, batch=3), dict(ordering=0)])
+@pytest.mark.parametrize("kw", [dict(ordering=1), dict(ordering=1, streams=2, batch=3), dict(ordering=0), dict(ordering=2), dict(ordering=2, streams=2, batch=3)])
 def test_queue_kernel_on_cluttered_scenes(pt, label, keep, kw):
     """The typed work queues on scenes that are nothing like the Cornell box: up to the 32 primitives the kernel takes, one
     type missing altogether, rays with many rival candidates (the in-place extra rounds), mirrors and glass."""
@@ -168,7 +168,7 @@ def test_queue_kernel_on_cluttered_scenes(pt, label, keep, kw):
     tr.close()
 
 
-@pytest.mark.parametrize("ordering", [0, 1])
+@pytest.mark.parametrize("ordering", [0, 1, 2])
 def test_depth_64_and_rays_that_all_miss(pt, ordering):
     """max_depth = 64 (the ABI's limit) on the mirror box, and a camera that looks away from everything"""
     sc = orc.load_golden_scene("cornell_mirror").with_resolution(64, 48)

@@ -8,6 +8,6 @@ import csv,glob,sys,collections
 agg=collections.defaultdict(float); n=0
 for f in glob.glob(sys.argv[1]+"/**/*counter_collection.csv",recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_bounce" in r["Kernel_Name"]: agg[r["Counter_Name"]]+=float(r["Counter_Value"])
+        if "k_bounce" in r["Kernel_Name"] or "k_path" in r["Kernel_Name"]: agg[r["Counter_Name"]]+=float(r["Counter_Value"])
 print(sys.argv[2], {k: round(v/1e6,1) for k,v in sorted(agg.items())}, "(millions, all bounce dispatches of the run: 5 warm-up + 2 x 20 steps)")
 PY
