@@ -188,7 +188,8 @@ def main():
     ap.add_argument("--chunk-rays", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--merge-floor", type=int, default=0)
-    ap.add_argument("--ordering", type=int, default=1, help="0 = stable compaction (library default), 1 = typed work queues (<= 32 primitives)")
+    ap.add_argument("--ordering", type=int, default=2, help="0 = stable compaction (library default), 1 = typed work queues, one launch per bounce (<= 32 primitives), "
+                                                             "2 = whole paths on the typed work queues, one launch per group (<= 32 primitives, no meshes; else like 1 / 0)")
     ap.add_argument("--batch", type=int, default=0, help="iterations per launch group (0 = auto, 1 = off)")
     ap.add_argument("--resolution", default="", help="WxH override of the scene RES line (experiments only)")
     ap.add_argument("--culling", type=int, default=0, help="0 = AABB candidate culling (default), 1 = brute force")
@@ -401,7 +402,7 @@ def main():
                              "kernel_only_frac": round(nbytes / (float(ev.bounce_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                              "note": "from one extra pass with HIP events around every launch on the render streams (slower than the value pass); "
                                      "kernel_only_frac = algorithmic bytes / the busiest stream's summed bounce-kernel time / 8 TB/s"}
-        roof = {"bound": "hbm", "kernel": "k_bounce_* (cull + exact tests + scatter + accumulate + segmented compaction; bounce 0 also generates)",
+        roof = {"bound": "hbm", "kernel": ("k_path_q (whole paths: generate + cull + exact tests + scatter + accumulate, rays between bounces on per-wave stacks)" if args.ordering == 2 and args.workload != "c4" and not args.direct_light else "k_bounce_* (cull + exact tests + scatter + accumulate + segmented compaction; bounce 0 also generates)"),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": provenance,
                 "algorithmic_bytes_per_step": round(nbytes / args.steps), "algorithmic_bytes_per_launch": round(nbytes / launches),
@@ -427,7 +428,7 @@ def main():
             "config": {"workload": desc, "scene": scene_path, "resolution": [W, H], "bounces": depth,
                        "rays_per_step": W * H, "sharding": "rows interleaved over %d GPU(s), 1 RCCL %s per frame (timed separately: see exchange)" % (world, "gather of the owned rows" if args.exchange == "gather" else "reduce"),
                        "live_ray_bounces_per_step": round(live_per_step),
-                       "compaction": ("segmented, wave-autonomous; " + {0: "stable order (ordering=0)", 1: "typed work queues (ordering=1)"}.get(args.ordering, "stable order")) if args.compaction == 0 else "global look-back scan",
+                       "compaction": ("segmented, wave-autonomous; " + {0: "stable order (ordering=0)", 1: "typed work queues, one launch per bounce (ordering=1)", 2: "whole paths on typed work queues, one launch per group (ordering=2; scenes above 32 primitives: stable order)"}.get(args.ordering, "stable order")) if args.compaction == 0 else "global look-back scan",
                        "direct_light": bool(args.direct_light), "streams_per_gpu": S,
                        "warmup_passes": "W steps + %d untimed K-step passes (same launch-group shape as the timed passes; until three in a row agree to 1 %%)" % warm_passes},
             "roofline": roof,

@@ -147,7 +147,7 @@ void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iteratio
             cfg.focal_distance = env_float("PT_FOCAL_DIST", 0.0f);
             cfg.direct_light = env_int("PT_DIRECT_LIGHT", 0);
             cfg.streams = env_int("PT_STREAMS", 2);
-            cfg.ordering = env_int("PT_ORDERING", 1);         // typed work queues: fastest, results identical
+            cfg.ordering = env_int("PT_ORDERING", 2);         // whole paths on the typed work queues: fastest, results identical
             cfg.row_offset = r;
             cfg.row_stride = ngpu;
             pt_context *c = nullptr;

@@ -1384,22 +1384,25 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : PT_Q_WAVES) void k_bounce_q(SegA
 // No barrier, no inter-wave traffic, no pool; per-level live counts through one LDS atomic per group.  Results: the same image, live
 // counts and emitter hits as every other kernel (the rays of a bounce are a set, not a sequence).
 #ifndef PT_P_CAP
-#define PT_P_CAP 152
+#define PT_P_CAP 128                     // records per wave (13 dwords each): 5 blocks = 20 waves per CU; 152 (4 blocks) and 104 (6) measured slower
 #endif
 constexpr uint32_t kPCap = PT_P_CAP;
 constexpr uint32_t kPFields = 13;        // ox oy oz dx dy dz tx ty tz pixelword mask candidate level
 constexpr uint32_t kStack = 256;         // rays on a wave's stack (bound: 63 + two pops of 64)
 constexpr uint32_t kSFields = 11;        // ox oy oz dx dy dz tx ty tz pixelword level
-#ifndef PT_P_JOB
-#define PT_P_JOB 512
-#endif
-constexpr uint32_t kJobRays = PT_P_JOB;       // camera rays per ticket
+constexpr uint32_t kTicketCtrs = 16, kTicketStride = 64;
+constexpr uint32_t kJobMax = 128;        // camera rays per job: about 1/48 of a wave's share of the launch, 64 .. kJobMax
 
 struct PathArgs {
     float *arena;                    // [waves][kSFields][kStack]
     uint32_t arena_bytes;            // != 0: below 4 GiB, buffer addressing
     uint32_t depth;
-    uint32_t *ticket;                // zero before the launch
+    uint32_t *ticket;                // kTicketCtrs counters, kTicketStride dwords apart (one cache line each), zero before the launch:
+                                     //   counter k hands out the drawn jobs k, k + kTicketCtrs, ... -- same-address device atomics are served
+                                     //   one after the other (~10 ns each), sixteen lines sixteen times as fast
+    uint32_t job_rays;               // camera rays per job (a multiple of 64)
+    uint32_t static_rounds;          // every wave's first jobs are its own (job = round * waves + slot): device atomics on ONE
+                                     //   address are served memory-side at ~8 ns each, so only the last part of a launch is drawn
     uint32_t *error;
 };
 
@@ -1468,6 +1471,12 @@ __global__ __launch_bounds__(kBlock, 4) void k_path_q(SegArgs a, PathArgs pa, co
     uint32_t sp = 0u;                                      // rays on the wave's stack
     uint32_t jobpos = 0u, jobend = 0u;
     bool tickets_left = true;
+    // the ticket of the NEXT job is requested one job ahead (lane 0 holds it): its latency passes under the current job
+    uint32_t next_ticket = 0u;
+    uint32_t round = 0u;                                   // static jobs taken so far
+    const uint32_t nwaves = gridDim.x * kWaves;
+    uint32_t ctr = wslot % kTicketCtrs, dry = 0u;          // the counter this wave draws from; counters found exhausted in a row
+    if (pa.static_rounds == 0u && lane == 0) next_ticket = atomicAdd(pa.ticket + ctr * kTicketStride, 1u);
     uint32_t turns = 0u;
     const float kInf = 100000000000000000.0f;
 
@@ -1479,13 +1488,23 @@ __global__ __launch_bounds__(kBlock, 4) void k_path_q(SegArgs a, PathArgs pa, co
         else if (nbox + nsph <= kPCap - 64u) {
             if (sp >= 64u) act = 0;
             else {
-                if (jobpos >= jobend && tickets_left) {                                    // next job of camera rays
-                    uint32_t t = 0u;
-                    if (lane == 0) t = atomicAdd(pa.ticket, 1u);
-                    t = __builtin_amdgcn_readfirstlane(t);
-                    const unsigned long long first = (unsigned long long)t * kJobRays;
-                    if (first >= (unsigned long long)a.n_rays) tickets_left = false;
-                    else { jobpos = (uint32_t)first; jobend = a.n_rays - jobpos < kJobRays ? a.n_rays : jobpos + kJobRays; }
+                while (jobpos >= jobend && tickets_left) {                                 // next job of camera rays (a dry counter: try the next)
+                    unsigned long long job;
+                    if (round < pa.static_rounds) {
+                        job = (unsigned long long)wslot * pa.static_rounds + round;       // the wave's own contiguous range: neighbouring rays take similar paths
+                        round++;
+                        if (round == pa.static_rounds && lane == 0) next_ticket = atomicAdd(pa.ticket + ctr * kTicketStride, 1u);      // first drawn job, one job ahead
+                    } else {
+                        job = (unsigned long long)pa.static_rounds * nwaves + (unsigned long long)__builtin_amdgcn_readfirstlane(next_ticket) * kTicketCtrs + ctr;
+                        if (job * pa.job_rays >= (unsigned long long)a.n_rays) {          // this counter is dry: on to the next one
+                            dry++;
+                            ctr = ctr + 1u == kTicketCtrs ? 0u : ctr + 1u;
+                            if (dry >= kTicketCtrs) tickets_left = false;
+                        } else dry = 0u;
+                        if (tickets_left && lane == 0) next_ticket = atomicAdd(pa.ticket + ctr * kTicketStride, 1u);
+                    }
+                    const unsigned long long first = job * pa.job_rays;
+                    if (first < (unsigned long long)a.n_rays) { jobpos = (uint32_t)first; jobend = a.n_rays - jobpos < pa.job_rays ? a.n_rays : jobpos + pa.job_rays; }
                 }
                 if (jobpos < jobend) act = 3;
                 else if (sp) act = 0;
@@ -1851,6 +1870,7 @@ struct pt_context {
     bool queue = false;              // typed work-queue kernel (cfg.ordering == 1; LDS geometry, G <= 32, no merging)
     bool pathq = false;              //   cfg.ordering == 2: whole paths in one launch (k_path_q), rings instead of pools
     float *d_arena = nullptr;        //   [grid_path * kWaves][kSFields][kStack]: the waves' ray stacks
+    uint32_t *d_tickets = nullptr;   //   [kTicketCtrs][kTicketStride]
     size_t arena_bytes = 0;
     int grid_path = 0;
     uint32_t lds_path = 0;
@@ -1958,6 +1978,8 @@ void free_scene_buffers(pt_context *c) {
     c->d_cull = nullptr;
     if (c->d_arena) (void)hipFree(c->d_arena);
     c->d_arena = nullptr;
+    if (c->d_tickets) (void)hipFree(c->d_tickets);
+    c->d_tickets = nullptr;
     for (void *b : c->d_mesh_blobs) (void)hipFree(b);
     c->d_mesh_blobs.clear();
     if (c->image == c->image_own) c->image = nullptr;
@@ -2258,10 +2280,22 @@ int enqueue_iterations(pt_context *c, uint32_t iteration, uint32_t batch, int st
         a.n_rays = n_rays; a.batch = batch; a.planes = c->d_planes; a.plane_stride = (size_t)c->n_own * 3;
         PathArgs pa;
         pa.arena = c->d_arena; pa.arena_bytes = c->arena_bytes < (1ull << 32) ? (uint32_t)c->arena_bytes : 0u;
-        pa.depth = (uint32_t)D; pa.ticket = &c->d_sync->tickets[0]; pa.error = &c->d_sync->error;
+        pa.depth = (uint32_t)D; pa.ticket = c->d_tickets; pa.error = &c->d_sync->error;
+        {   // job size: about 48 jobs per wave of the launch, whole groups, 64 .. kJobMax rays
+            const uint64_t per_wave = (uint64_t)n_rays / ((uint64_t)c->grid_path * kWaves * 48u);
+            uint32_t job = (uint32_t)((per_wave + 63u) & ~63ull);
+            if (job < 64u) job = 64u;
+            if (job > kJobMax) job = kJobMax;
+            if (c->cfg.chunk_rays > 0) job = (uint32_t)((c->cfg.chunk_rays + 63) & ~63);      // explicit
+            pa.job_rays = job;
+            // static share: half of the jobs (cfg.merge_floor = -n: n eighths, -9: none -- experiments)
+            const uint64_t njobs = ((uint64_t)n_rays + job - 1) / job, waves = (uint64_t)c->grid_path * kWaves;
+            const uint32_t eighths = c->cfg.merge_floor == -9 ? 0u : c->cfg.merge_floor < 0 ? (uint32_t)(-c->cfg.merge_floor) : 4u;
+            pa.static_rounds = (uint32_t)(njobs * (eighths > 8u ? 8u : eighths) / 8u / waves);
+        }
         QTables qt;
         qt.frames = c->d_frames; qt.cull = c->d_cull; qt.nbox = c->q_nbox; qt.nsph = c->q_nsph;
-        HIPCHK(hipMemsetAsync(pa.ticket, 0, sizeof(uint32_t), c->stream));
+        HIPCHK(hipMemsetAsync(pa.ticket, 0, (size_t)kTicketCtrs * kTicketStride * sizeof(uint32_t), c->stream));
         {
             Scoped s(c, 1);
             hipLaunchKernelGGL(k_path_q, dim3(c->grid_path), dim3(kBlock), c->lds_path, c->stream, a, pa,
@@ -2786,6 +2820,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         c->grid_path = c->n_cu * occ;
         c->arena_bytes = (size_t)c->grid_path * kWaves * (size_t)kSFields * kStack * sizeof(float);
         HIPCHK(hipMalloc(&c->d_arena, c->arena_bytes));
+        HIPCHK(hipMalloc(&c->d_tickets, (size_t)kTicketCtrs * kTicketStride * sizeof(uint32_t)));
     }
     pth::camera_basis(cam, &c->cfg, &c->cam);
     c->scene_ready = true;

@@ -40,7 +40,7 @@ struct Options {
     std::string scene, outdir, devices;
     int frame = 0;
     bool single_frame = false;
-    int depth, mode, camera_mode, aa, gpus, device, iterations = 0, ordering = 1, batch = -1, raw = 0, direct = 0, streams = 2;
+    int depth, mode, camera_mode, aa, gpus, device, iterations = 0, ordering = 2, batch = -1, raw = 0, direct = 0, streams = 2;
     float aperture, focal;
 };
 

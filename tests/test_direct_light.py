@@ -156,6 +156,7 @@ def test_no_emitters_means_no_contribution():
     ("cornell_glass_4k", 12, 3, dict(camera_mode=1, antialias=1, aperture=0.25, focal_distance=12.0)),
     ("random256", 8, 2, dict()),
     ("sampleScene", 2, 3, dict(ordering=1)),                           # ordering is ignored, not an error
+    ("sampleScene", 3, 2, dict(ordering=2)),
 ])
 def test_gpu_image_and_live_counts_match_oracle(pt, name, depth, iters, kw):
     sc = orc.load_golden_scene(name).with_resolution(160, 120)

@@ -161,7 +161,7 @@ def test_image_and_live_counts_match_oracle(pt, scene_name, depth, iters):
     assert not np.isnan(img).any()
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(ordering=1), dict(direct_light=1)])
+@pytest.mark.parametrize("kw", [dict(), dict(ordering=1), dict(ordering=2), dict(direct_light=1)])
 def test_long_launch_groups_use_every_slot_bit(pt, kw):
     """Small frames batch up to 128 iterations into one launch group (slot = bits 24..30 of the pixel
     word, bit 31 = the direct-light flag): 150 iterations = one full group + a partial one."""
@@ -190,7 +190,7 @@ def test_accumulation_continues_from_host_image(pt, cornell200):
 
 
 @pytest.mark.parametrize("kw", [dict(geometry_path=1), dict(chunk_rays=64), dict(batch=1), dict(batch=2), dict(batch=3, chunk_rays=100), dict(chunk_rays=64, merge_floor=3000), dict(chunk_rays=64, merge_floor=50, batch=2), dict(chunk_rays=1000), dict(chunk_rays=16, merge_floor=1), dict(chunk_rays=100, merge_floor=7), dict(blocks_per_cu=1),
-                                dict(culling=1), dict(culling=1, geometry_path=1), dict(ordering=1), dict(ordering=1, batch=2), dict(ordering=1, chunk_rays=100, merge_floor=7), dict(ordering=1, batch=1, chunk_rays=64), dict(ordering=1, chunk_rays=128, blocks_per_cu=1), dict(ordering=1, batch=5, blocks_per_cu=2),
+                                dict(culling=1), dict(culling=1, geometry_path=1), dict(ordering=1), dict(ordering=1, batch=2), dict(ordering=1, chunk_rays=100, merge_floor=7), dict(ordering=1, batch=1, chunk_rays=64), dict(ordering=1, chunk_rays=128, blocks_per_cu=1), dict(ordering=1, batch=5, blocks_per_cu=2), dict(ordering=2), dict(ordering=2, batch=2), dict(ordering=2, batch=1, chunk_rays=64), dict(ordering=2, chunk_rays=192, blocks_per_cu=1), dict(ordering=2, batch=5, blocks_per_cu=2, merge_floor=-9), dict(ordering=2, merge_floor=-8),
                                 dict(compaction=1), dict(compaction=1, chunk_rays=256), dict(compaction=1, chunk_rays=1024, geometry_path=1)])
 def test_launch_variants_are_bit_identical(pt, cornell200, kw):
     ref = make_tracer(cornell200)
@@ -238,7 +238,7 @@ def test_row_sharded_contexts_sum_to_the_full_frame(pt, cornell200):
     assert np.array_equal(total, want)
 
 
-@pytest.mark.parametrize("contexts,kw", [(2, dict(ordering=1)), (3, dict()), (2, dict(direct_light=1))])
+@pytest.mark.parametrize("contexts,kw", [(2, dict(ordering=1)), (3, dict()), (2, dict(direct_light=1)), (3, dict(ordering=2))])
 def test_concurrent_contexts_share_one_device_image(pt, contexts, kw):
     """What bench.py --streams does: several contexts on ONE device, each on its own stream and owning every
     n-th row, all bound to the same device accumulator and enqueued before any is awaited.  Their launches
@@ -274,7 +274,7 @@ def test_concurrent_contexts_share_one_device_image(pt, contexts, kw):
     hip.hipFree(dptr)
 
 
-@pytest.mark.parametrize("streams,kw,depth", [(2, dict(ordering=1), 8), (3, dict(), 6), (2, dict(direct_light=1), 6),
+@pytest.mark.parametrize("streams,kw,depth", [(2, dict(ordering=1), 8), (3, dict(), 6), (2, dict(direct_light=1), 6), (2, dict(ordering=2), 8), (3, dict(row_offset=2, row_stride=3, ordering=2, batch=2), 5),
                                                (2, dict(row_offset=1, row_stride=2, ordering=1), 6), (4, dict(batch=3), 5)])
 def test_streams_inside_one_context_are_bit_identical(pt, streams, kw, depth):
     """pt_config.streams: the context shards its rows over internal contexts on separate streams sharing one image.
@@ -371,7 +371,7 @@ def test_full_size_properties_1080p(pt):
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(batch=2, chunk_rays=100), dict(geometry_path=1), dict(culling=1), dict(streams=2), dict(direct_light=1),
-                                dict(ordering=1), dict(ordering=1, batch=3, chunk_rays=128), dict(ordering=1, streams=2)])
+                                dict(ordering=1), dict(ordering=1, batch=3, chunk_rays=128), dict(ordering=1, streams=2), dict(ordering=2)])
 def test_many_primitives_scene_matches_oracle(pt, kw):
     """BASELINE config 4's scene (256 spheres+cubes incl. rotated cubes, mirrors, glass): the two-level
     candidate culling must never change the nearest hit."""

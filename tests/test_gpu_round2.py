@@ -238,7 +238,7 @@ def test_fold_of_batched_iterations_at_odd_widths(pt, w, h):
     """Batched iterations at frame widths that are no multiple of anything: the per-slot planes hold the owned pixels only,
     the fold adds them in iteration order -- image bit-identical to the oracle's one-iteration-after-the-other accumulation."""
     sc = orc.load_golden_scene("cornell_mirror").with_resolution(w, h)
-    for kw in (dict(batch=5), dict(batch=4, streams=2, ordering=1), dict(batch=7, ordering=1, row_offset=1, row_stride=3)):
+    for kw in (dict(batch=5), dict(batch=4, streams=2, ordering=1), dict(batch=7, ordering=1, row_offset=1, row_stride=3), dict(batch=6, ordering=2, row_offset=2, row_stride=3)):
         tr = make_tracer(sc, depth=5, **kw)
         tr.set_image(None)
         tr.render(1, 9)

@@ -14,7 +14,7 @@ world, S, steps, passes = (int(KW.pop(k, d)) for k, d in (("world", 8), ("stream
 KW = {k: int(v) for k, v in KW.items()}
 sf = pkg.SceneFile(os.path.join(ROOT, "scenes", "cornell_mirror.txt"))
 g, m, cam = sf.flatten(0)
-tr = pkg.PathTracer(pkg.default_config(max_depth=8, ordering=1, row_offset=0, row_stride=world, streams=S, **KW))
+tr = pkg.PathTracer(pkg.default_config(**dict(dict(max_depth=8, ordering=1, row_offset=0, row_stride=world, streams=S), **KW)))
 tr.upload(g, m, cam)
 tr.set_image(None)
 tr.render(1, 5)

@@ -27,7 +27,7 @@ def short(name):
         if len(flags) > 3 and flags[3]:
             tag += ",gen"
         return tag + ">"
-    for k in ("k_generate", "k_flat", "k_display"):
+    for k in ("k_path_q", "k_generate", "k_flat", "k_display"):
         if k in name:
             return k
     return name[:60]
@@ -46,7 +46,7 @@ def main():
         # the launch sequence of one render iteration (generate + bounces), from the tail of the trace
         rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
         seq = [(short(r["Kernel_Name"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
-                int(r["Start_Timestamp"])) for r in rows if "k_bounce" in r["Kernel_Name"] or "k_generate" in r["Kernel_Name"]]
+                int(r["Start_Timestamp"])) for r in rows if "k_bounce" in r["Kernel_Name"] or "k_path" in r["Kernel_Name"] or "k_generate" in r["Kernel_Name"]]
         gens = [i for i, x in enumerate(seq) if x[0] == "k_generate"]
         if len(gens) >= 3:
             a, b = gens[-3], gens[-2]

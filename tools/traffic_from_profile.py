@@ -15,7 +15,7 @@ d = json.load(open(os.path.join(ROOT, "profiles", tag + "_summary.json")))
 tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "SQ_INSTS_VALU": 0.0}
 dispatches = 0
 for name, o in d["pmc"].items():
-    if not name.startswith("k_bounce"):
+    if not (name.startswith("k_bounce") or name.startswith("k_path")):
         continue
     for c in tot:
         if c in o:
@@ -30,7 +30,7 @@ rec[workload] = {
     "valu_wave_instructions_per_step": round(tot["SQ_INSTS_VALU"] / steps),
     "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of the bench.py command in tools/profile.sh (%s, bench "
            "defaults); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch (gfx950 FETCH_SIZE counts 64 B per 128-B request on wide "
-           "coalesced reads; WRITE_SIZE exact), summed over all k_bounce_* dispatches of the %d rendered steps and divided by %d; "
+           "coalesced reads; WRITE_SIZE exact), summed over all k_bounce_* / k_path_q dispatches of the %d rendered steps and divided by %d; "
            "bench.py scales it to its own launch count (bytes per step x steps / launches)" % (tag, steps, steps)}
 json.dump(rec, open(path, "w"), indent=1)
 print({k: v for k, v in rec[workload].items() if k != "how"})
