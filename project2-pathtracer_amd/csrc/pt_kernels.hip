@@ -1873,6 +1873,7 @@ struct pt_context {
     uint32_t *d_tickets = nullptr;   //   [kTicketCtrs][kTicketStride]
     size_t arena_bytes = 0;
     int grid_path = 0;
+    uint32_t path_static_eighths = 4;
     uint32_t lds_path = 0;
     bool flat_pool = false;          //   PT_FLAT_POOL=1 (read at upload): 64-bit flat addressing of the pool even below 4 GiB (A/B switch)
     bool queue_mesh = false;         //   its variant with mesh traversal (scene has MESH primitives with triangles)
@@ -2288,10 +2289,9 @@ int enqueue_iterations(pt_context *c, uint32_t iteration, uint32_t batch, int st
             if (job > kJobMax) job = kJobMax;
             if (c->cfg.chunk_rays > 0) job = (uint32_t)((c->cfg.chunk_rays + 63) & ~63);      // explicit
             pa.job_rays = job;
-            // static share: half of the jobs (cfg.merge_floor = -n: n eighths, -9: none -- experiments)
+            // static share: half of the jobs (PT_P_STATIC_EIGHTHS = 0..8, read at upload: A/B switch and test hook)
             const uint64_t njobs = ((uint64_t)n_rays + job - 1) / job, waves = (uint64_t)c->grid_path * kWaves;
-            const uint32_t eighths = c->cfg.merge_floor == -9 ? 0u : c->cfg.merge_floor < 0 ? (uint32_t)(-c->cfg.merge_floor) : 4u;
-            pa.static_rounds = (uint32_t)(njobs * (eighths > 8u ? 8u : eighths) / 8u / waves);
+            pa.static_rounds = (uint32_t)(njobs * c->path_static_eighths / 8u / waves);
         }
         QTables qt;
         qt.frames = c->d_frames; qt.cull = c->d_cull; qt.nbox = c->q_nbox; qt.nsph = c->q_nsph;
@@ -2821,6 +2821,8 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         c->arena_bytes = (size_t)c->grid_path * kWaves * (size_t)kSFields * kStack * sizeof(float);
         HIPCHK(hipMalloc(&c->d_arena, c->arena_bytes));
         HIPCHK(hipMalloc(&c->d_tickets, (size_t)kTicketCtrs * kTicketStride * sizeof(uint32_t)));
+        c->path_static_eighths = 4u;
+        if (const char *ev = getenv("PT_P_STATIC_EIGHTHS")) { const int v = atoi(ev); c->path_static_eighths = v < 0 ? 0u : v > 8 ? 8u : (uint32_t)v; }
     }
     pth::camera_basis(cam, &c->cfg, &c->cam);
     c->scene_ready = true;

@@ -190,7 +190,7 @@ def test_accumulation_continues_from_host_image(pt, cornell200):
 
 
 @pytest.mark.parametrize("kw", [dict(geometry_path=1), dict(chunk_rays=64), dict(batch=1), dict(batch=2), dict(batch=3, chunk_rays=100), dict(chunk_rays=64, merge_floor=3000), dict(chunk_rays=64, merge_floor=50, batch=2), dict(chunk_rays=1000), dict(chunk_rays=16, merge_floor=1), dict(chunk_rays=100, merge_floor=7), dict(blocks_per_cu=1),
-                                dict(culling=1), dict(culling=1, geometry_path=1), dict(ordering=1), dict(ordering=1, batch=2), dict(ordering=1, chunk_rays=100, merge_floor=7), dict(ordering=1, batch=1, chunk_rays=64), dict(ordering=1, chunk_rays=128, blocks_per_cu=1), dict(ordering=1, batch=5, blocks_per_cu=2), dict(ordering=2), dict(ordering=2, batch=2), dict(ordering=2, batch=1, chunk_rays=64), dict(ordering=2, chunk_rays=192, blocks_per_cu=1), dict(ordering=2, batch=5, blocks_per_cu=2, merge_floor=-9), dict(ordering=2, merge_floor=-8),
+                                dict(culling=1), dict(culling=1, geometry_path=1), dict(ordering=1), dict(ordering=1, batch=2), dict(ordering=1, chunk_rays=100, merge_floor=7), dict(ordering=1, batch=1, chunk_rays=64), dict(ordering=1, chunk_rays=128, blocks_per_cu=1), dict(ordering=1, batch=5, blocks_per_cu=2), dict(ordering=2), dict(ordering=2, batch=2), dict(ordering=2, batch=1, chunk_rays=64), dict(ordering=2, chunk_rays=192, blocks_per_cu=1), dict(ordering=2, batch=5, blocks_per_cu=2),
                                 dict(compaction=1), dict(compaction=1, chunk_rays=256), dict(compaction=1, chunk_rays=1024, geometry_path=1)])
 def test_launch_variants_are_bit_identical(pt, cornell200, kw):
     ref = make_tracer(cornell200)

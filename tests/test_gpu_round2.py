@@ -246,3 +246,24 @@ def test_fold_of_batched_iterations_at_odd_widths(pt, w, h):
         want, _ = orc.render(sc, oracle_config(5, **okw), 1, 9)
         assert np.array_equal(tr.image(), want), (w, h, kw)
         tr.close()
+
+
+@pytest.mark.parametrize("eighths", ["0", "8", "3"])
+def test_whole_path_kernel_job_hand_out_all_drawn_all_static_and_mixed(pt, eighths):
+    """ordering = 2: the jobs of camera rays are partly the waves' own contiguous ranges, partly drawn from sixteen ticket
+    counters (PT_P_STATIC_EIGHTHS, read at upload).  Whatever the split -- all drawn, all static but the remainder, mixed --
+    every camera ray is rendered exactly once: image and live counts are the oracle's."""
+    sc = orc.load_golden_scene("cornell_mirror").with_resolution(213, 117)
+    os.environ["PT_P_STATIC_EIGHTHS"] = eighths
+    try:
+        for kw in (dict(ordering=2, batch=4), dict(ordering=2, streams=2, batch=3, chunk_rays=64), dict(ordering=2, batch=1, blocks_per_cu=1)):
+            tr = make_tracer(sc, depth=6, **kw)
+            tr.set_image(None)
+            tr.render(1, 7)
+            want, live = orc.render(sc, oracle_config(6), 1, 7)
+            st = tr.stats()
+            assert [st.live[k] for k in range(7)] == [int(v) for v in live], (eighths, kw)
+            assert np.array_equal(tr.image(), want), (eighths, kw)
+            tr.close()
+    finally:
+        del os.environ["PT_P_STATIC_EIGHTHS"]
