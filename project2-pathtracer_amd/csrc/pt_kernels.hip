@@ -1571,6 +1571,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_path_q(SegArgs a, PathArgs pa, co
             }
             if (!valid) mask = 0u;
             const bool push = mask != 0u;
+#ifdef PT_CULL_STATS
+            qstat(8, 1ull); qstat(9, (unsigned long long)__popcll(__ballot(valid)));
+            atomicAdd(&g_cull_stats[5], (unsigned long long)__popc(mask));
+            if (act == 3) qstat(6, 1ull);
+#endif
             mask &= ~(1u << next_j);
             const bool tobox = push && ((boxbits >> next_j) & 1u);
             const u64 bb = __ballot(tobox), sb = __ballot(push && !tobox);
@@ -1601,6 +1606,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_path_q(SegArgs a, PathArgs pa, co
         const bool valid = lane < cnt;
         const uint32_t pos = isb ? (have - cnt + lane) : (kPCap - 1u - (have - cnt + lane));
         if (isb) nbox -= cnt; else nsph -= cnt;
+#ifdef PT_CULL_STATS
+        qstat(isb ? 10 : 12, 1ull); qstat(isb ? 11 : 13, (unsigned long long)cnt);
+#endif
         f3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(0, 0, 0);
         uint32_t pv = 0u, mask = 0u, level = 0u;
         int j = 0;
@@ -1661,6 +1669,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_path_q(SegArgs a, PathArgs pa, co
                 if (wins) { best = depth; hit = j; P = p; N = nn; face = fc; }
             }
         }
+#ifdef PT_CULL_STATS
+        qstat(14, (unsigned long long)__popcll(__ballot(hit >= 0)));
+        qstat(7, (unsigned long long)__popcll(__ballot(hit >= 0 && level + 1u >= D)));
+#endif
         // shade the hits (the ray's own level is its bounce index)
         bool alive = false;
         if (hit >= 0) {

@@ -1,12 +1,14 @@
 """Stage statistics of the typed work-queue kernel (diagnostic).  Needs a library built with -DPT_CULL_STATS:
     tools/build_variant.sh stats -DPT_CULL_STATS
-    PTMI355_LIB=$PWD/project2-pathtracer_amd/build/variants/stats.so python3 tools/qstats.py [scene] [depth]"""
+    PTMI355_LIB=$PWD/project2-pathtracer_amd/build/variants/stats.so python3 tools/qstats.py [scene] [depth] [ordering: 1 per bounce, 2 whole paths]
+(ordering 2: "retests" = camera-ray groups, "candidates left" = shaded lanes at the last level)"""
 import ctypes as C, importlib, os, sys
 sys.path.insert(0, os.getcwd())
 pkg = importlib.import_module("project2-pathtracer_amd")
 sf = pkg.SceneFile(sys.argv[1] if len(sys.argv) > 1 else "scenes/cornell_mirror.txt"); g, m, cam = sf.flatten(0)
 depth = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-tr = pkg.PathTracer(pkg.default_config(max_depth=depth, ordering=1)); tr.upload(g, m, cam); tr.set_image(None)
+ordering = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+tr = pkg.PathTracer(pkg.default_config(max_depth=depth, ordering=ordering)); tr.upload(g, m, cam); tr.set_image(None)
 tr.render(1, 16); tr.sync()
 st = tr.stats()
 live = sum(st.live[k] for k in range(depth))
