@@ -1410,6 +1410,9 @@ __host__ __device__ inline uint32_t p_cursor_offset(int G, int M) { return q_lds
 __host__ __device__ inline uint32_t p_queue_offset(int G, int M) { return p_cursor_offset(G, M); }
 __host__ __device__ inline uint32_t p_lds_bytes(int G, int M) { return p_queue_offset(G, M) + (uint32_t)kWaves * kPCap * kPFields * 4u; }
 
+// MESH: the scene holds MESH primitives with triangles (they share the spheres' stack; the traversal needs registers the
+// common variant must not pay for)
+template <bool MESH>
 __global__ __launch_bounds__(kBlock, 4) void k_path_q(SegArgs a, PathArgs pa, const GeomRec *__restrict__ geoms,
                                                       const MatRec *__restrict__ mats, QTables qt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1462,9 +1465,12 @@ __global__ __launch_bounds__(kBlock, 4) void k_path_q(SegArgs a, PathArgs pa, co
         other[threadIdx.x] = 0u;
         if (threadIdx.x == 0) bank[0] = a.n_rays;
     }
-    uint32_t boxbits = 0u;
-    for (int j = 0; j < a.G; ++j)
+    uint32_t boxbits = 0u, meshbits = 0u;
+    for (int j = 0; j < a.G; ++j) {
         if (lg[j].type == 1) boxbits |= 1u << j;
+        else if (MESH && lg[j].type == 2 && lg[j].inside_hits != 0) meshbits |= 1u << j;
+    }
+    const uint32_t aabbbits = boxbits | meshbits;         // primitives whose conservative bound is a box
 
     uint32_t emitted = 0u;
     uint32_t nbox = 0u, nsph = 0u;
@@ -1630,8 +1636,12 @@ __global__ __launch_bounds__(kBlock, 4) void k_path_q(SegArgs a, PathArgs pa, co
         {
             const GeomRec *gr = lg + j;
             float depth = -1.0f;
+            const bool jm = MESH && ((meshbits >> j) & 1u);
             if (isb) { if (valid) depth = box_test_face(gr->inv, gr->xf, gr->inside_hits, o, d, P, face); }
-            else { if (valid) depth = sphere_test(gr->inv, gr->xf, o, d, P, N); }
+            else {
+                if (!MESH || __any(valid && !jm)) { if (valid && !jm) depth = sphere_test(gr->inv, gr->xf, o, d, P, N); }
+                if (MESH) { if (__any(valid && jm)) { if (valid && jm) depth = mesh_test(gr, o, d, P, N); } }
+            }
             const bool wins = valid && depth > -PT_EPSILON && depth < kInf;
             best = wins ? depth : kInf;
             hit = wins ? j : -1;
@@ -1649,7 +1659,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_path_q(SegArgs a, PathArgs pa, co
                         m &= m - 1u;
                         const GeomRec *gb = lg + jj;
                         float tn;
-                        if ((boxbits >> jj) & 1u) (void)cull_box(gb->bmin, gb->bmax, cr, tn);
+                        if ((aabbbits >> jj) & 1u) (void)cull_box(gb->bmin, gb->bmax, cr, tn);
                         else (void)cull_sphere(gb->bmin, gb->bmax, cr, tn);
                         if (hit >= 0 && tn - gb->slack > best) { mask &= ~(1u << jj); continue; }
                         if (tn < nt) { nt = tn; next_j = jj; }
@@ -1659,12 +1669,14 @@ __global__ __launch_bounds__(kBlock, 4) void k_path_q(SegArgs a, PathArgs pa, co
                 if (!__any(active)) break;
                 if (active) { j = next_j; mask &= ~(1u << next_j); }
                 const bool jb = (boxbits >> j) & 1u;
+                const bool jm = MESH && ((meshbits >> j) & 1u);
                 const GeomRec *gr = lg + j;
                 f3 p = mk(0, 0, 0), nn = mk(0, 0, 0);
                 int fc = -1;
                 float depth = -1.0f;
                 if (__any(active && jb)) { if (active && jb) depth = box_test_face(gr->inv, gr->xf, gr->inside_hits, o, d, p, fc); }
-                if (__any(active && !jb)) { if (active && !jb) depth = sphere_test(gr->inv, gr->xf, o, d, p, nn); }
+                if (__any(active && !jb && !jm)) { if (active && !jb && !jm) depth = sphere_test(gr->inv, gr->xf, o, d, p, nn); }
+                if (MESH) { if (__any(active && jm)) { if (active && jm) depth = mesh_test(gr, o, d, p, nn); } }
                 const bool wins = active && depth > -PT_EPSILON && (depth < best || (depth == best && j < hit));
                 if (wins) { best = depth; hit = j; P = p; N = nn; face = fc; }
             }
@@ -2310,8 +2322,12 @@ int enqueue_iterations(pt_context *c, uint32_t iteration, uint32_t batch, int st
         HIPCHK(hipMemsetAsync(pa.ticket, 0, (size_t)kTicketCtrs * kTicketStride * sizeof(uint32_t), c->stream));
         {
             Scoped s(c, 1);
-            hipLaunchKernelGGL(k_path_q, dim3(c->grid_path), dim3(kBlock), c->lds_path, c->stream, a, pa,
-                               (const GeomRec *)c->d_geoms, (const MatRec *)c->d_mats, qt);
+            if (c->queue_mesh)
+                hipLaunchKernelGGL(k_path_q<true>, dim3(c->grid_path), dim3(kBlock), c->lds_path, c->stream, a, pa,
+                                   (const GeomRec *)c->d_geoms, (const MatRec *)c->d_mats, qt);
+            else
+                hipLaunchKernelGGL(k_path_q<false>, dim3(c->grid_path), dim3(kBlock), c->lds_path, c->stream, a, pa,
+                                   (const GeomRec *)c->d_geoms, (const MatRec *)c->d_mats, qt);
             HIPCHK(hipGetLastError());
         }
         if (batch > 1u) {
@@ -2823,12 +2839,12 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         HIPCHK(hipMemcpy(c->d_cull, cr.data(), cr.size() * sizeof(CullRec), hipMemcpyHostToDevice));
     }
     // ordering = 2: whole paths in one launch -- a persistent grid of its own and the waves' level rings
-    c->pathq = c->queue && !c->queue_mesh && c->cfg.ordering == 2 && !c->nee;
+    c->pathq = c->queue && c->cfg.ordering == 2 && !c->nee;
     if (c->pathq) {
         c->lds_path = p_lds_bytes(G, M);
         int occ = 0;
         if (c->cfg.blocks_per_cu > 0) occ = c->cfg.blocks_per_cu;
-        else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(&k_path_q), kBlock, c->lds_path) != hipSuccess || occ < 1) occ = 2;
+        else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, c->queue_mesh ? reinterpret_cast<const void *>(&k_path_q<true>) : reinterpret_cast<const void *>(&k_path_q<false>), kBlock, c->lds_path) != hipSuccess || occ < 1) occ = 2;
         c->grid_path = c->n_cu * occ;
         c->arena_bytes = (size_t)c->grid_path * kWaves * (size_t)kSFields * kStack * sizeof(float);
         HIPCHK(hipMalloc(&c->d_arena, c->arena_bytes));
