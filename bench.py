@@ -370,11 +370,11 @@ def main():
             try:
                 rec = json.load(open(tpath)).get(args.workload, {})
                 current = kernel_source_id()
-                stale = rec.get("kernel_source_id") != current
+                stale = rec.get("kernel_source_id") != current or (rec.get("ordering") is not None and rec.get("ordering") != args.ordering)
                 provenance = {"file": "profiles/traffic_latest.json", "profile": rec.get("profile"), "steps_profiled": rec.get("steps_profiled"),
                               "kernel_source_id": rec.get("kernel_source_id"), "current_kernel_source_id": current, "stale": stale,
                               "note": "counter figures come from a SEPARATE rocprofv3 --pmc run of this command (tools/profile.sh), scaled per step; "
-                                      "they are dropped (null) when the kernels have changed since that run"}
+                                      "they are dropped (null) when the kernels have changed since that run or the run used another --ordering"}
                 if not stale:
                     per_step = rec.get("hbm_bytes_per_step")
                     traffic = round(per_step * args.steps / launches) if per_step else None
