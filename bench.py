@@ -196,9 +196,10 @@ def main():
     ap.add_argument("--compaction", type=int, default=0, help="0 = segmented (default), 1 = look-back scan")
     ap.add_argument("--exchange", default="gather", choices=["gather", "reduce"],
                     help="N > 1 frame exchange: gather = owned rows to rank 0 (default), reduce = full-frame sum")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=0,
                     help="contexts per GPU, each on its own HIP stream and owning every (streams*gpus)-th row: the tails of one "
-                         "context's launches are filled by the other's (bit-identical, like the multi-GPU sharding); 1 = off")
+                         "context's launches are filled by the other's (bit-identical, like the multi-GPU sharding); 1 = off; "
+                         "0 = auto: 2 when a rank renders at least 30 M camera rays per timed pass, else 1 (measured: tools/shard_sim.py)")
     ap.add_argument("--direct-light", type=int, default=0, help="1 = next-event estimation (one shadow ray per diffuse hit); not the headline configuration")
     ap.add_argument("--warm-passes", type=int, default=0, help="untimed K-step passes before the timed ones (0 = until the pass time has settled; profiling runs fix it)")
     ap.add_argument("--repeats", type=int, default=7, help="the exact K-step timed pass is repeated this many times; value = the median pass")
@@ -258,7 +259,7 @@ def main():
 
     # S streams per GPU (pt_config.streams): the context shards this rank's rows once more over S internal contexts,
     # each on its own HIP stream, all rendering straight into the same device accumulator.
-    S = max(1, args.streams)
+    S = args.streams if args.streams > 0 else (2 if (W * H // world) * args.steps >= 30_000_000 else 1)
     accum = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda:%d" % device)
     tracer = pkg.PathTracer(pkg.default_config(device=device, max_depth=depth, row_offset=rank, row_stride=world, streams=S,
                                                geometry_path=args.geometry_path, chunk_rays=args.chunk_rays,
