@@ -30,8 +30,9 @@ extern "C" {
  * pt_config_default() first, so that fields added later keep their defaults
  * 3: + pt_get_rows, pt_gather_rows_peer (the per-frame exchange of a row-sharded render)
  * 4: + pt_mesh, pt_set_meshes, pt_scene_mesh_count, pt_scene_mesh (GEOMTYPE MESH)
- * 5: ordering 2 / 3 and bvh 1 / 2 (round-1 experiments, all slower than what replaced them) are gone; the fields stay */
-#define PTMI355_ABI_VERSION 5
+ * 5: ordering 2 / 3 and bvh 1 / 2 (round-1 experiments, all slower than what replaced them) are gone; the fields stay
+ * 6: ordering = 2 is back with a new meaning: whole paths on the typed work queues, one launch per group */
+#define PTMI355_ABI_VERSION 6
 
 typedef enum {
     PT_OK = 0,
