@@ -95,7 +95,7 @@ def test_owned_row_exchange_host_and_peer(pt, streams):
 @pytest.mark.parametrize("kw", [dict(ordering=1, streams=2), dict(ordering=0, streams=2), dict(ordering=1, streams=1),
                                 dict(direct_light=1, streams=2), dict(ordering=2, streams=1), dict(ordering=2, streams=2)])
 def test_headline_launch_variant_full_size_against_oracle_rows(pt, kw):
-    """What bench.py times (configs[2] at 1920x1080, ordering=1, streams=2, automatic batching over a
+    """What bench.py times (configs[2] at 1920x1080, ordering=2 -- and its predecessors ordering=1 / 0 --, streams=2, automatic batching over a
     20-iteration launch group) against the oracle on an interleave of rows (VERDICT r1 weak #8)."""
     sc = orc.load_golden_scene("cornell_mirror")
     assert (sc.W, sc.H) == (1920, 1080)
