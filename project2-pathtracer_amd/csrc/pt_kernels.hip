@@ -1384,10 +1384,10 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : PT_Q_WAVES) void k_bounce_q(SegA
 // No barrier, no inter-wave traffic, no pool; per-level live counts through one LDS atomic per group.  Results: the same image, live
 // counts and emitter hits as every other kernel (the rays of a bounce are a set, not a sequence).
 #ifndef PT_P_CAP
-#define PT_P_CAP 128                     // records per wave (13 dwords each): 5 blocks = 20 waves per CU; 152 (4 blocks) and 104 (6) measured slower
+#define PT_P_CAP 138                     // records per wave (12 dwords each): 5 blocks = 20 waves per CU; 4 blocks with more records and 6 with fewer measured slower
 #endif
 constexpr uint32_t kPCap = PT_P_CAP;
-constexpr uint32_t kPFields = 13;        // ox oy oz dx dy dz tx ty tz pixelword mask candidate level
+constexpr uint32_t kPFields = 12;        // ox oy oz dx dy dz tx ty tz pixelword mask candidate|level<<8
 constexpr uint32_t kStack = 256;         // rays on a wave's stack (bound: 63 + two pops of 64)
 constexpr uint32_t kSFields = 11;        // ox oy oz dx dy dz tx ty tz pixelword level
 constexpr uint32_t kTicketCtrs = 16, kTicketStride = 64;
@@ -1594,8 +1594,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_path_q(SegArgs a, PathArgs pa, co
                     r[6 * kPCap] = thr.x; r[7 * kPCap] = thr.y; r[8 * kPCap] = thr.z;
                     r[9 * kPCap] = __uint_as_float(pv);
                     r[10 * kPCap] = __uint_as_float(mask);
-                    r[11 * kPCap] = __uint_as_float(next_j);
-                    r[12 * kPCap] = __uint_as_float(level);
+                    r[11 * kPCap] = __uint_as_float(next_j | (level << 8));
                 }
                 nbox += (uint32_t)__popcll(bb);
                 nsph += (uint32_t)__popcll(sb);
@@ -1626,8 +1625,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_path_q(SegArgs a, PathArgs pa, co
             thr = mk(r[6 * kPCap], r[7 * kPCap], r[8 * kPCap]);
             pv = __float_as_uint(r[9 * kPCap]);
             mask = __float_as_uint(r[10 * kPCap]);
-            j = (int)__float_as_uint(r[11 * kPCap]);
-            level = __float_as_uint(r[12 * kPCap]);
+            const uint32_t jl = __float_as_uint(r[11 * kPCap]);
+            j = (int)(jl & 0xFFu);
+            level = jl >> 8;
         }
         __builtin_amdgcn_wave_barrier();
         float best;
