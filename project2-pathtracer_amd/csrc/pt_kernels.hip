@@ -831,7 +831,8 @@ __global__ __launch_bounds__(kBlock, (NEE || WIDE) ? 4 : PT_SEG_WAVES) void k_bo
 }
 
 // ------------------------------------------------------------------ bounce, typed work queues ----
-// `ordering = 1` (what bench.py runs).  Measured on the Cornell box (tools/qstats.py): a ray has 0.93 candidate
+// `ordering = 1` (one launch per bounce; k_path_q below runs the same two stages over whole paths and is what bench.py
+// runs).  Measured on the Cornell box (tools/qstats.py): a ray has 0.93 candidate
 // primitives on average -- a third have none, most of the rest exactly one, 0.82 exact tests per ray are needed in
 // all -- yet in the lock-step kernels every 64-ray group pays whole rounds of the exact cube test, the exact sphere
 // test and the shading for the lanes that need them.  Here the unit of work is ONE EXACT TEST of a ray against its
