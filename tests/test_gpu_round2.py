@@ -286,3 +286,18 @@ def test_whole_path_kernel_equals_the_stable_kernel_on_full_frames(pt):
         b.close()
         assert np.array_equal(ia, ib), name
         assert [sa.live[k] for k in range(depth + 1)] == [sb.live[k] for k in range(depth + 1)] and sa.emitted == sb.emitted, name
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3])
+def test_whole_path_kernel_at_the_smallest_depths(pt, depth):
+    """max_depth 1 (every ray is at its last level from the start: nothing ever goes on the stack), 2 and 3."""
+    sc = orc.load_golden_scene("sampleScene").with_resolution(150, 100)
+    for kw in (dict(ordering=2), dict(ordering=2, streams=2, batch=3)):
+        tr = make_tracer(sc, depth=depth, **kw)
+        tr.set_image(None)
+        tr.render(1, 4)
+        want, live = orc.render(sc, oracle_config(depth), 1, 4)
+        st = tr.stats()
+        assert [st.live[k] for k in range(depth + 1)] == [int(v) for v in live], (depth, kw)
+        assert np.array_equal(tr.image(), want), (depth, kw)
+        tr.close()
