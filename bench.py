@@ -40,9 +40,13 @@ WORKLOADS = {
     "c2": ("scenes/cornell.txt", 8, "configs[1]: sampleScene-equivalent Cornell box 800x800, 8 bounces, diffuse only"),
     "c4": ("scenes/random256.txt", 8, "configs[3]: 1920x1080, 8 bounces, 256 random spheres+cubes"),
     "c5": ("scenes/cornell_glass_4k.txt", 16, "configs[4]: 3840x2160, 16 bounces, Fresnel refraction + depth of field + jittered AA"),
+    # GEOMTYPE MESH (the reference declares the type and leaves its kernel branch empty): not a BASELINE config
+    "mesh": ("scenes/cornell_mesh.txt", 8, "MESH: Cornell box 1920x1080, 8 bounces, icosphere (80 triangles) + torus (400) + glass tetrahedron beside a sphere and a cube"),
+    "mesh5k": ("scenes/cornell_mesh5k.txt", 8, "MESH: Cornell box 1920x1080, 8 bounces, one 5 120-triangle icosphere beside a sphere and a cube"),
 }
 # render options a workload needs beyond scene + depth (the reference has no channel for them)
 WORKLOAD_OPTIONS = {"c5": dict(camera_mode=1, antialias=1, aperture=0.25, focal_distance=12.0)}
+WORKLOAD_RESOLUTION = {"mesh": "1920x1080", "mesh5k": "1920x1080"}       # these scene files carry a small preview RES
 
 
 def reduce_to_root(tensor, dst=0):
@@ -54,38 +58,63 @@ def reduce_to_root(tensor, dst=0):
     return tensor
 
 
-def gather_rows_to_root(tensor, H, W, dst=0):
+class RowGather:
     """Per-frame exchange, cheaper form: every rank sends only the rows it owns (y % world == rank,
     1/world of the frame) straight to rank `dst`, which copies them into its full-frame accumulator.
     On the point-to-point xGMI fabric the peers' sends use distinct links in parallel (24.9 MB / 8 =
     3.1 MB per link at 1080p) where a reduce moves the whole frame across every hop.
     No arithmetic at all, so the result is trivially bit-identical to a single-GPU render.
-    `tensor`: this rank's flat float32 [H*W*3] accumulator."""
-    import torch
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+
+    Allocation-free in the timed region: the packed send buffer and rank `dst`'s [world, rows, W*3] receive
+    buffer are allocated ONCE here; a call is one strided pack copy per rank, one gather, and on `dst` one
+    strided copy into the frame (a permuted view [world, rows, W*3] of the accumulator when world divides H,
+    else one copy per peer)."""
+
+    def __init__(self, like, H, W, dst=0):
+        import torch
+        import torch.distributed as dist
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if not self.active:
+            return
+        self.world, self.rank, self.dst, self.H, self.W = dist.get_world_size(), dist.get_rank(), dst, H, W
+        self.max_rows = (H + self.world - 1) // self.world
+        self.send = torch.zeros((self.max_rows, W * 3), dtype=like.dtype, device=like.device)
+        self.recv = torch.empty((self.world, self.max_rows, W * 3), dtype=like.dtype, device=like.device) if self.rank == dst else None
+        self.recv_list = list(self.recv.unbind(0)) if self.rank == dst else None
+
+    def __call__(self, tensor):
+        """`tensor`: this rank's flat float32 [H*W*3] accumulator (same device / dtype as at construction)."""
+        import torch.distributed as dist
+        if not self.active:
+            return tensor
+        frame = tensor.view(self.H, self.W * 3)
+        mine = frame[self.rank::self.world]
+        self.send[:mine.shape[0]].copy_(mine)
+        dist.gather(self.send, self.recv_list, dst=self.dst)
+        if self.rank == self.dst:
+            if self.H % self.world == 0:
+                # row y = k*world + r  ->  [k, r, :]; peers' rows in one strided copy, own rows written back unchanged
+                self.recv[self.dst].copy_(mine)
+                frame.view(self.max_rows, self.world, self.W * 3).permute(1, 0, 2).copy_(self.recv)
+            else:
+                for r in range(self.world):
+                    if r != self.dst:
+                        frame[r::self.world] = self.recv[r][:len(range(r, self.H, self.world))]
         return tensor
-    world, rank = dist.get_world_size(), dist.get_rank()
-    frame = tensor.view(H, W * 3)
-    max_rows = (H + world - 1) // world
-    mine = frame[rank::world]
-    send = torch.zeros((max_rows, W * 3), dtype=tensor.dtype, device=tensor.device)
-    send[:mine.shape[0]] = mine
-    recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
-    dist.gather(send, recv, dst=dst)
-    if rank == dst:
-        for r in range(world):
-            if r != dst:
-                frame[r::world] = recv[r][:len(range(r, H, world))]
-    return tensor
+
+
+def gather_rows_to_root(tensor, H, W, dst=0):
+    """One-off form of RowGather (tests): allocates its buffers per call."""
+    return RowGather(tensor, H, W, dst)(tensor)
 
 
 def kernel_source_id():
     """sha256[:16] of the kernel sources: ties borrowed counter figures (profiles/traffic_latest.json) to a build"""
     import hashlib
     h = hashlib.sha256()
-    for name in ("pt_kernels.hip", "pt_device.hpp"):
-        with open(os.path.join(ROOT, "project2-pathtracer_amd", "csrc", name), "rb") as f:
+    csrc = os.path.join(ROOT, "project2-pathtracer_amd", "csrc")
+    for name in sorted(n for n in os.listdir(csrc) if n.startswith("pt_k") or n == "pt_device.hpp"):     # kernel families + shared device code
+        with open(os.path.join(csrc, name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
 
@@ -118,7 +147,7 @@ def cpu_baseline(scene_path, depth, budget_s=15.0, options=None):
     import numpy as np
     import orc
     pkg = importlib.import_module("project2-pathtracer_amd")
-    sf = pkg.SceneFile(os.path.join(ROOT, scene_path))
+    sf = pkg.SceneFile(scene_path if os.path.isabs(scene_path) else os.path.join(ROOT, scene_path))
     geoms, mats, cam = sf.flatten(0)
     og = (orc.Geom * len(geoms))()
     for i, g in enumerate(geoms):
@@ -184,16 +213,16 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events in the timed region")
-    ap.add_argument("--geometry-path", type=int, default=0)
     ap.add_argument("--chunk-rays", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
-    ap.add_argument("--merge-floor", type=int, default=0)
     ap.add_argument("--ordering", type=int, default=2, help="0 = stable compaction (library default), 1 = typed work queues, one launch per bounce (<= 32 primitives), "
-                                                             "2 = whole paths on the typed work queues, one launch per group (<= 32 primitives, no meshes; else like 1 / 0)")
+                                                             "2 = whole paths, one launch per group: k_path_q (<= 32 primitives) / k_path_w (33..256 analytic primitives)")
+    ap.add_argument("--wide-variant", type=int, default=0, help="k_path_w block shape (A/B switch, results identical)")
+    ap.add_argument("--cluster-size", type=int, default=0, help="members per spatial cluster for scenes of 33..256 primitives (0 = default)")
+    ap.add_argument("--static-eighths", type=int, default=4, help="whole-path kernels: eighths of the camera-ray jobs owned statically by the waves")
     ap.add_argument("--batch", type=int, default=0, help="iterations per launch group (0 = auto, 1 = off)")
     ap.add_argument("--resolution", default="", help="WxH override of the scene RES line (experiments only)")
     ap.add_argument("--culling", type=int, default=0, help="0 = AABB candidate culling (default), 1 = brute force")
-    ap.add_argument("--compaction", type=int, default=0, help="0 = segmented (default), 1 = look-back scan")
     ap.add_argument("--exchange", default="gather", choices=["gather", "reduce"],
                     help="N > 1 frame exchange: gather = owned rows to rank 0 (default), reduce = full-frame sum")
     ap.add_argument("--streams", type=int, default=0,
@@ -202,6 +231,7 @@ def main():
                          "0 = auto: 2 when a rank renders at least 30 M camera rays per timed pass, else 1 (measured: tools/shard_sim.py)")
     ap.add_argument("--direct-light", type=int, default=0, help="1 = next-event estimation (one shadow ray per diffuse hit); not the headline configuration")
     ap.add_argument("--warm-passes", type=int, default=0, help="untimed K-step passes before the timed ones (0 = until the pass time has settled; profiling runs fix it)")
+    ap.add_argument("--dump-image", default="", help="rank 0 writes the frame it holds after the per-frame exchange (float32 .npy, H x W x 3): parity tests of the N > 1 path")
     ap.add_argument("--repeats", type=int, default=7, help="the exact K-step timed pass is repeated this many times; value = the median pass")
     args = ap.parse_args()
 
@@ -244,15 +274,20 @@ def main():
     scene_path, depth, desc = WORKLOADS[args.workload]
     options = WORKLOAD_OPTIONS.get(args.workload, {})
     scene_file = os.path.join(ROOT, scene_path)
+    args.resolution = args.resolution or WORKLOAD_RESOLUTION.get(args.workload, "")
     if args.resolution:
         import re
         import tempfile
         w_, h_ = args.resolution.lower().split("x")
         text = re.sub(r"RES\s+\d+\s+\d+", "RES         %d %d" % (int(w_), int(h_)), open(scene_file).read())
-        tmp = tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False)
+        # beside the original, so that relative `*.obj` names still resolve
+        tmp = tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False, dir=os.path.dirname(scene_file), prefix=".bench_r%d_" % int(os.environ.get("RANK", "0")))
         tmp.write(text); tmp.close()
         scene_file = tmp.name
-        desc += " [RES overridden to %s]" % args.resolution
+        import atexit
+        atexit.register(lambda f=tmp.name: os.path.exists(f) and os.remove(f))
+        if args.workload not in WORKLOAD_RESOLUTION:
+            desc += " [RES overridden to %s]" % args.resolution
     sf = pkg.SceneFile(scene_file)
     geoms, mats, cam = sf.flatten(0)
     W, H = int(cam.resolution[0]), int(cam.resolution[1])
@@ -262,9 +297,12 @@ def main():
     S = args.streams if args.streams > 0 else (2 if (W * H // world) * args.steps >= 30_000_000 else 1)
     accum = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda:%d" % device)
     tracer = pkg.PathTracer(pkg.default_config(device=device, max_depth=depth, row_offset=rank, row_stride=world, streams=S,
-                                               geometry_path=args.geometry_path, chunk_rays=args.chunk_rays,
-                                               blocks_per_cu=args.blocks_per_cu, culling=args.culling, merge_floor=args.merge_floor, batch=args.batch, ordering=args.ordering,
-                                               compaction=args.compaction, direct_light=args.direct_light, **options))
+                                               chunk_rays=args.chunk_rays, blocks_per_cu=args.blocks_per_cu, culling=args.culling, batch=args.batch,
+                                               ordering=args.ordering, direct_light=args.direct_light, wide_variant=args.wide_variant,
+                                               cluster_size=args.cluster_size, path_static_eighths=args.static_eighths, **options))
+    meshes = sf.meshes()
+    if meshes:
+        tracer.set_meshes(meshes)
     tracer.upload(geoms, mats, cam)
     tracer.bind_device_image(accum)
 
@@ -275,8 +313,10 @@ def main():
     # warm-up (untimed)
     tracer.render(1, args.warmup)
     tracer.sync()
+    row_gather = RowGather(accum if backend == "nccl" else accum.cpu(), H, W)     # buffers allocated once, outside any timed region
+
     def exchange(t):
-        return gather_rows_to_root(t, H, W) if args.exchange == "gather" else reduce_to_root(t)
+        return row_gather(t) if args.exchange == "gather" else reduce_to_root(t)
 
     if world > 1 and backend == "nccl":
         exchange(accum.clone())                # RCCL communicator setup outside the timed region
@@ -309,12 +349,14 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         if backend == "nccl":
-            exchange(accum)
+            gathered[0] = exchange(accum)
         else:                                   # CPU rehearsal of the N>1 path (gloo)
-            exchange(accum.cpu())
+            gathered[0] = exchange(accum.cpu())
         torch.cuda.synchronize()
         barrier()
         return max_over_ranks(time.perf_counter() - t0)
+
+    gathered = [None]
 
     # 0) untimed passes of the SAME K-step shape until the pass time has settled (the W warm-up steps above form a
     #    differently sized launch group, and a cold chip ramps its clock over the first tens of milliseconds: seven
@@ -339,6 +381,10 @@ def main():
     raw = tracer.stats()                          # counters of the last pass: every pass renders the same iterations
     # N > 1: the frame exchange, once per frame (see the module docstring); three measurements, the median counts
     exchange_s = sorted(timed_exchange() for _ in range(3))[1] if world > 1 else 0.0
+    if args.dump_image and rank == 0:
+        import numpy as np
+        frame = gathered[0] if world > 1 else accum
+        np.save(args.dump_image, frame.detach().cpu().numpy().reshape(H, W, 3))
     frame_iterations = max(int(sf.iterations), args.steps)
     elapsed_frame_share = elapsed + exchange_s * args.steps / frame_iterations
     # 2) the same K steps once more with every launch bracketed by HIP events on the render stream: per-launch
@@ -356,7 +402,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         t = [int(v) for v in t.tolist()]
         stats.live, stats.emitted, stats.bounce_launches = t[:65], t[65], t[66]
-    nbytes, design_bytes, live = algorithmic_bytes(stats, depth, fused_generate=(args.compaction == 0))
+    nbytes, design_bytes, live = algorithmic_bytes(stats, depth)
     result = None
     if rank == 0:
         value = W * H * args.steps * depth / elapsed_frame_share / 1e6
@@ -366,31 +412,56 @@ def main():
         traffic = None
         valu = None
         provenance = None
+        hbm_measured = None
+        nprims = len(geoms)
+        # which kernel family rendered (mirrors pt_upload_scene's choice)
+        if args.ordering == 2 and not args.direct_light and nprims <= 32:
+            kernel = "k_path_q (whole paths, one launch per group: generate + cull + exact tests + scatter + accumulate; rays between bounces on per-wave stacks)"
+        elif args.ordering == 2 and not args.direct_light and nprims <= 256 and not meshes:
+            kernel = "k_path_w (whole paths, one launch per group, 33..256 primitives: cluster culling, dense (ray, cluster) pairs, type-pure exact tests, shading; rays between bounces on per-wave stacks)"
+        elif args.ordering in (1, 2) and not args.direct_light and nprims <= 32:
+            kernel = "k_bounce_q (typed work queues, one launch per bounce)"
+        else:
+            kernel = "k_bounce_seg (cull + exact tests + scatter + accumulate + segmented compaction, one launch per bounce; bounce 0 also generates)"
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if world == 1 and os.path.exists(tpath):
             try:
                 rec = json.load(open(tpath)).get(args.workload, {})
                 current = kernel_source_id()
-                stale = rec.get("kernel_source_id") != current or (rec.get("ordering") is not None and rec.get("ordering") != args.ordering)
+                stale = rec.get("kernel_source_id") != current or (rec.get("ordering") is not None and rec.get("ordering") != args.ordering) \
+                    or bool(rec.get("direct_light", 0)) != bool(args.direct_light)
                 provenance = {"file": "profiles/traffic_latest.json", "profile": rec.get("profile"), "steps_profiled": rec.get("steps_profiled"),
                               "kernel_source_id": rec.get("kernel_source_id"), "current_kernel_source_id": current, "stale": stale,
-                              "note": "counter figures come from a SEPARATE rocprofv3 --pmc run of this command (tools/profile.sh), scaled per step; "
+                              "note": "counter figures come from a SEPARATE rocprofv3 --pmc run of this command (tools/profile.sh), per rendered step; "
                                       "they are dropped (null) when the kernels have changed since that run or the run used another --ordering"}
                 if not stale:
                     per_step = rec.get("hbm_bytes_per_step")
-                    traffic = round(per_step * args.steps / launches) if per_step else None
+                    if per_step:
+                        traffic = round(per_step)
+                        gbs = per_step * args.steps / elapsed / 1e9
+                        hbm_measured = {"bytes_per_step": round(per_step), "GB_s": round(gbs, 1), "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4),
+                                        "ratio_to_algorithmic_bytes": round(per_step * args.steps / max(1, nbytes), 3),
+                                        "note": "HBM bytes from the PMC counters, (2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch in separate passes (MI355X_MICROARCH.md, HBM), "
+                                                "per rendered step, over the wall time of the value pass: THIS is the achieved HBM bandwidth against the chip's peak"}
                     vi = rec.get("valu_wave_instructions_per_step")
                     if vi:
-                        # secondary bound: wave64 VALU issue.  The non-packed f32 rate behind the
-                        # guide's 78.6 TFLOP/s is one wave64 instruction per 4 cycles per SIMD (16 lanes/clk);
-                        # plain mul/add/mov issue in ~2 cycles (tools/ubench/pk_rate.hip), the hard ceiling.
+                        # what actually bounds these kernels: wave64 VALU issue (SURVEY.md 8d's secondary bound).  Datasheet rate: one
+                        # wave64 instruction per 2 cycles per SIMD (MI355X_MICROARCH.md: SIMD-32, 2 cycles); measured ceiling on the
+                        # kernels' own exact-test bodies: tools/ubench/valu_ceiling.hip -> profiles/valu_ceiling.json
                         rate = vi * args.steps / elapsed
+                        ns_per = elapsed * 1024.0 / (vi * args.steps) * 1e9
                         valu = {"wave_instructions_per_step": vi, "achieved_G_wave_inst_per_s": round(rate / 1e9, 1),
                                 "peak_G_wave_inst_per_s": 1228.8, "frac": round(rate / 1.2288e12, 4),
-                                "frac_of_4_cycle_issue": round(rate / 0.6144e12, 4),
+                                "ns_per_wave_instruction_per_simd": round(ns_per, 3),
                                 "wave_instructions_per_64_live_ray_bounces": round(vi / max(1.0, sum(live[:depth]) / max(1, stats.iterations) / 64.0), 1),
-                                "note": "instruction count from rocprofv3 SQ_INSTS_VALU (see traffic_source), duration = the value pass; peak = 1024 SIMDs x 2.4 GHz / 2 cycles, "
-                                        "frac_of_4_cycle_issue = against one wave64 instruction per 4 cycles per SIMD (the non-packed f32 rate)"}
+                                "note": "instruction count from rocprofv3 SQ_INSTS_VALU (see traffic_source), duration = the value pass; peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction"}
+                        cpath = os.path.join(ROOT, "profiles", "valu_ceiling.json")
+                        if os.path.exists(cpath):
+                            ceil = json.load(open(cpath))
+                            lo, hi = float(ceil["ns_per_wave_instruction_per_simd"]["best"]), float(ceil["ns_per_wave_instruction_per_simd"]["worst"])
+                            valu["measured_ceiling_ns_per_wave_instruction_per_simd"] = [lo, hi]
+                            valu["frac_of_measured_ceiling"] = [round(lo / ns_per, 4), round(hi / ns_per, 4)]
+                            valu["measured_ceiling_source"] = ceil.get("source")
             except Exception:
                 traffic = None
         kernel_events = None
@@ -403,9 +474,19 @@ def main():
                              "kernel_only_frac": round(nbytes / (float(ev.bounce_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                              "note": "from one extra pass with HIP events around every launch on the render streams (slower than the value pass); "
                                      "kernel_only_frac = algorithmic bytes / the busiest stream's summed bounce-kernel time / 8 TB/s"}
-        roof = {"bound": "hbm", "kernel": ("k_path_q (whole paths: generate + cull + exact tests + scatter + accumulate, rays between bounces on per-wave stacks)" if args.ordering == 2 and args.workload != "c4" and not args.direct_light else "k_bounce_* (cull + exact tests + scatter + accumulate + segmented compaction; bounce 0 also generates)"),
+        # `bound`: what the counters say limits the kernel.  Every kernel of this path tracer is limited by vector-instruction
+        # issue (IEEE-exact intersection arithmetic), not by HBM; `frac` stays SURVEY.md 8(d)'s HBM-roofline figure (a work rate in
+        # survey-byte units, mostly served from L2 / LDS / registers), the measured HBM bandwidth is `hbm_measured`.
+        bound = "valu-issue"
+        if hbm_measured and valu and hbm_measured["frac_of_peak"] > valu["frac"]:
+            bound = "hbm"
+        roof = {"bound": bound, "stated_roofline": "hbm (SURVEY.md 8(d) algorithmic bytes / 8 TB/s): `achieved`, `peak`, `frac` below are in those units",
+                "kernel": kernel,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": provenance,
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic, "traffic_per_launch": (round(traffic * args.steps / launches) if traffic else None),
+                "traffic_units": "HBM bytes per rendered step (PMC); traffic_per_launch = x steps / launches",
+                "hbm_measured": hbm_measured, "traffic_source": provenance,
                 "algorithmic_bytes_per_step": round(nbytes / args.steps), "algorithmic_bytes_per_launch": round(nbytes / launches),
                 "duration": "wall time of the median K-step pass = the pass `value` and `ms_per_step` come from (launch gaps and k_fold included): "
                             "frac = algorithmic_bytes_per_step / ms_per_step / 8e12",
@@ -413,7 +494,7 @@ def main():
                 "design_moved": {"bytes_per_step": round(design_bytes / args.steps),
                                  "achieved": round(design_bytes / elapsed / 1e9, 1),
                                  "frac": round(design_bytes / elapsed / 1e9 / HBM_PEAK_GBS, 4),
-                                 "note": "bytes this implementation actually has to move (fused generation, no write-back at the last bounce, accumulator touched by emitter hits only)"},
+                                 "note": "bytes a per-bounce pool implementation has to move (fused generation, no write-back at the last bounce, accumulator touched by emitter hits only)"},
                 "launches": launches, "counters": "live rays, emitter hits and launches summed over all %d rank(s)" % world, "kernel_events": kernel_events, "valu_issue": valu}
         live_per_step = sum(live[:depth]) / max(1, int(stats.iterations))
         result = {
@@ -429,7 +510,8 @@ def main():
             "config": {"workload": desc, "scene": scene_path, "resolution": [W, H], "bounces": depth,
                        "rays_per_step": W * H, "sharding": "rows interleaved over %d GPU(s), 1 RCCL %s per frame (timed separately: see exchange)" % (world, "gather of the owned rows" if args.exchange == "gather" else "reduce"),
                        "live_ray_bounces_per_step": round(live_per_step),
-                       "compaction": ("segmented, wave-autonomous; " + {0: "stable order (ordering=0)", 1: "typed work queues, one launch per bounce (ordering=1)", 2: "whole paths on typed work queues, one launch per group (ordering=2; scenes above 32 primitives: stable order)"}.get(args.ordering, "stable order")) if args.compaction == 0 else "global look-back scan",
+                       "compaction": "wave-autonomous (ballot + mbcnt ranks); " + {0: "stable order, one launch per bounce (ordering=0)", 1: "typed work queues, one launch per bounce (ordering=1)", 2: "whole paths, one launch per group (ordering=2)"}.get(args.ordering, "stable order"),
+                       "primitives": nprims,
                        "direct_light": bool(args.direct_light), "streams_per_gpu": S,
                        "warmup_passes": "W steps + %d untimed K-step passes (same launch-group shape as the timed passes; until three in a row agree to 1 %%)" % warm_passes},
             "roofline": roof,
@@ -444,8 +526,13 @@ def main():
                 "share_charged_to_value_ms": round(exchange_s * args.steps / frame_iterations * 1e3, 6),
                 "k_steps_only_ms": round(elapsed * 1e3, 4),
                 "value_if_exchanged_every_pass": round(W * H * args.steps * depth / (elapsed + exchange_s) / 1e6, 1)}
+            # both accountings in plain view at the top level
+            result["value_if_exchanged_every_pass"] = result["exchange"]["value_if_exchanged_every_pass"]
+            result["exchange_accounting"] = ("`value` charges the per-frame exchange (%.3f ms) at its share of a %d-iteration frame: t = t_K + t_exchange * K / %d; "
+                                             "`value_if_exchanged_every_pass` charges one whole exchange to the %d timed steps"
+                                             % (exchange_s * 1e3, frame_iterations, frame_iterations, args.steps))
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(scene_path, depth, options=options)
+            result["cpu_baseline"] = cpu_baseline(scene_file, depth, options=options) if not meshes else None    # the oracle's mesh entry point is exercised in tests/, not timed here
         print(json.dumps(result), flush=True)
     tracer.close()
     if world > 1:

@@ -31,8 +31,11 @@ extern "C" {
  * 3: + pt_get_rows, pt_gather_rows_peer (the per-frame exchange of a row-sharded render)
  * 4: + pt_mesh, pt_set_meshes, pt_scene_mesh_count, pt_scene_mesh (GEOMTYPE MESH)
  * 5: ordering 2 / 3 and bvh 1 / 2 (round-1 experiments, all slower than what replaced them) are gone; the fields stay
- * 6: ordering = 2 is back with a new meaning: whole paths on the typed work queues, one launch per group */
-#define PTMI355_ABI_VERSION 6
+ * 6: ordering = 2 is back with a new meaning: whole paths on the typed work queues, one launch per group
+ * 7: geometry_path, compaction = 1 (look-back scan) and merge_floor are gone (measured slower; the fields stay and
+ *    must be 0); reserved[3] became cluster_size / path_static_eighths / wide_variant (they replace environment
+ *    switches the library used to read); ordering = 2 also covers scenes of 33..256 analytic primitives (k_path_w) */
+#define PTMI355_ABI_VERSION 7
 
 typedef enum {
     PT_OK = 0,
@@ -94,16 +97,16 @@ typedef struct {
     float focal_distance;
     int   row_offset;        /* multi-GPU: this context owns rows y with y % row_stride == */
     int   row_stride;        /*   row_offset (single GPU: 0, 1) */
-    int   geometry_path;     /* 0 = LDS-staged geometry table (default), 1 = scalar loads */
-    int   chunk_rays;        /* slots per level-0 pool segment (default 192) / rays per look-back ticket */
+    int   geometry_path;     /* removed in ABI 7, must be 0: the geometry table lives in LDS whenever it fits (about
+                                1 100 primitives); larger scenes use scalar loads automatically */
+    int   chunk_rays;        /* slots per pool segment (0 = by launch size) / camera rays per job of the whole-path kernels */
     int   blocks_per_cu;     /* persistent grid size = CUs * this (0 = default) */
     int   profile;           /* 1 = bracket every kernel launch with HIP events */
-    int   compaction;        /* 0 = wave-autonomous segmented compaction (default)
-                                1 = global decoupled look-back scan (dense pool) */
+    int   compaction;        /* removed in ABI 7, must be 0: wave-autonomous segmented compaction (ballot + mbcnt ranks
+                                inside a wave, one wave per pool segment) is the only form */
     int   culling;           /* 0 = conservative AABB candidate culling before the exact tests (default;
                                 results identical), 1 = brute force over all primitives */
-    int   merge_floor;       /* segmented mode, optional: a bounce merges neighbouring segments while the
-                                halved segment count stays >= this (0 = never merge, the default) */
+    int   merge_floor;       /* removed in ABI 7, must be 0 */
     int   batch;             /* iterations that may share one launch group in pt_render (0 = auto: about
                                 32 M rays per launch, at most 128; 1 = one iteration per launch).  Results
                                 are identical: each in-flight iteration accumulates into its own plane
@@ -116,8 +119,9 @@ typedef struct {
                                     results identical).
                                 2 = whole paths on the typed work queues: ONE launch per group; waves draw jobs of camera
                                     rays from a ticket counter and keep every ray from the camera to its end (queue records
-                                    carry the ray and its bounce level, survivors wait in small per-wave rings per level);
-                                    same conditions as 1, no meshes; results identical.  Other values behave like 0. */
+                                    carry the ray and its bounce level, survivors wait on small per-wave stacks);
+                                    <= 32 primitives: k_path_q; 33..256 analytic primitives: k_path_w (dense (ray, cluster)
+                                    pairs, type-pure exact tests on full waves); results identical.  Other values behave like 0. */
     int   bvh;               /* unused (round-1 experiments, removed); scenes with 33..256 analytic primitives use
                                 two-level cluster culling automatically, meshes carry their own BVH */
     int   direct_light;      /* 1 = next-event estimation: at every diffuse hit one shadow
@@ -130,7 +134,12 @@ typedef struct {
                                 internal contexts, each on its own stream, all rendering into the same image and
                                 all enqueued before any is awaited: the tails of one stream's launches are filled
                                 by the others' (mode 0; bit-identical; parity hooks need 1).  DESIGN.md section 4. */
-    int   reserved[3];
+    int   cluster_size;      /* scenes of 33..256 primitives: preferred members per spatial cluster of the two-level
+                                culling (0 = default; the library grows it until the clusters fit their mask) */
+    int   path_static_eighths; /* whole-path kernels: share of the camera-ray jobs every wave owns statically, in
+                                eighths (pt_config_default: 4 = half); the rest is drawn from ticket counters */
+    int   wide_variant;      /* k_path_w block shape: 0 = default, 1..3 = other waves-per-block / ray-slot splits of
+                                the CU's LDS (A/B switch; results identical) */
 } pt_config;
 
 typedef struct pt_context pt_context;
@@ -221,6 +230,10 @@ int  pt_debug_primary_hits(pt_context *ctx, float *dir, int *hit, float *t, floa
 int  pt_debug_trace_pool(pt_context *ctx, int iteration, int bounces, int *count,
                          float *ox, float *oy, float *oz, float *dx, float *dy, float *dz,
                          float *tr, float *tg, float *tb, uint32_t *pixel);
+/* The whole-path kernels (ordering = 2) bound the scheduling turns a wave may take, so that a broken build ends with
+ * PT_ERR_HIP ("turn limit reached") at the next pt_sync instead of hanging the device.  0 = sized by the launch (default);
+ * tests lower it to provoke the guard. */
+int  pt_debug_set_turn_limit(pt_context *ctx, unsigned int turns);
 /* generateRandomNumberFromThread (src/raytraceKernel.cu:30-37) evaluated on the device for n
  * (x,y) pairs. */
 int  pt_debug_rng_from_thread(pt_context *ctx, float resx, float resy, float time, int n,

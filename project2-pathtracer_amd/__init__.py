@@ -47,7 +47,8 @@ class Config(C.Structure):     # == pt_config
                 ("antialias", C.c_int), ("aperture", C.c_float), ("focal_distance", C.c_float),
                 ("row_offset", C.c_int), ("row_stride", C.c_int), ("geometry_path", C.c_int),
                 ("chunk_rays", C.c_int), ("blocks_per_cu", C.c_int), ("profile", C.c_int),
-                ("compaction", C.c_int), ("culling", C.c_int), ("merge_floor", C.c_int), ("batch", C.c_int), ("ordering", C.c_int), ("bvh", C.c_int), ("direct_light", C.c_int), ("streams", C.c_int), ("reserved", C.c_int * 3)]
+                ("compaction", C.c_int), ("culling", C.c_int), ("merge_floor", C.c_int), ("batch", C.c_int), ("ordering", C.c_int), ("bvh", C.c_int), ("direct_light", C.c_int), ("streams", C.c_int),
+                ("cluster_size", C.c_int), ("path_static_eighths", C.c_int), ("wide_variant", C.c_int)]
 
 
 class Mesh(C.Structure):       # == pt_mesh
@@ -103,6 +104,7 @@ def lib():
     L.pt_get_resolution.argtypes = [vp, ip, ip, ip]
     L.pt_debug_primary_hits.argtypes = [vp, fp, ip, fp, fp, fp]
     L.pt_debug_trace_pool.argtypes = [vp, C.c_int, C.c_int, ip] + [fp] * 9 + [C.POINTER(C.c_uint32)]
+    L.pt_debug_set_turn_limit.argtypes = [vp, C.c_uint]
     L.pt_debug_rng_from_thread.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_int, ip, fp]
     L.pt_debug_hemisphere.argtypes = [vp, C.c_int, fp, fp, fp]
     L.pt_debug_sincos.argtypes = [vp, C.c_int, fp, fp, fp]
@@ -124,7 +126,7 @@ EXPORTS = [
     "pt_abi_version", "pt_last_error", "pt_config_default", "pt_device_count", "pt_create", "pt_destroy",
     "pt_upload_scene", "pt_set_meshes", "pt_scene_mesh_count", "pt_scene_mesh", "pt_set_image", "pt_bind_device_image", "pt_get_image", "pt_get_rows", "pt_gather_rows_peer", "pt_render", "pt_sync",
     "pt_display", "pt_set_profiling", "pt_get_stats", "pt_reset_stats", "pt_get_resolution", "pt_debug_primary_hits",
-    "pt_debug_trace_pool", "pt_debug_rng_from_thread", "pt_debug_hemisphere", "pt_debug_sincos", "pt_debug_light_points",
+    "pt_debug_trace_pool", "pt_debug_set_turn_limit", "pt_debug_rng_from_thread", "pt_debug_hemisphere", "pt_debug_sincos", "pt_debug_light_points",
     "pt_scene_load", "pt_scene_free", "pt_scene_counts", "pt_scene_image_name", "pt_scene_flatten",
     "pt_scene_object_matrices", "pt_build_transform", "pt_image_to_u8", "pt_image_save",
 ]
@@ -290,6 +292,9 @@ class PathTracer:
         _check(lib().pt_debug_trace_pool(self._h, iteration, bounces, C.byref(cnt), *[_fp(a) for a in arrs],
                                          pix.ctypes.data_as(C.POINTER(C.c_uint32))))
         return cnt.value, [a[:cnt.value] for a in arrs], pix[:cnt.value]
+
+    def set_turn_limit(self, turns):
+        _check(lib().pt_debug_set_turn_limit(self._h, int(turns)))
 
     def rng_from_thread(self, resx, resy, time, xy):
         xy = np.ascontiguousarray(xy, np.int32)

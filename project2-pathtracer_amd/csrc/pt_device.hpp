@@ -14,7 +14,7 @@
 #include "pt_camrec.hpp"
 
 // Every function here is host-callable too: the host evaluates per-primitive constants (the box-face
-// shading frames, pt_kernels.hip) with the very same expression trees, compiled by the same hipcc run with
+// shading frames, pt_api.hip) with the very same expression trees, compiled by the same hipcc run with
 // the same -ffp-contract=off, so a tabulated value has the bits the kernel would have computed.
 #define PTD_FN __host__ __device__ __forceinline__
 
@@ -336,7 +336,7 @@ PTD_FN bool sample_light(const float *xf, int type, float randomSeed, f3 &Q, flo
 
 // ---------------------------------------------------------------- scatter --------------
 // calculateRandomDirectionInHemisphere (src/interactions.h:62-87), in two halves: the tangent frame depends only
-// on the normal (tabulated per box face by the host, pt_kernels.hip), the combination on the two random numbers.
+// on the normal (tabulated per box face by the host, pt_api.hip), the combination on the two random numbers.
 PTD_FN void hemisphere_frame(f3 normal, f3 &p1, f3 &p2) {
     f3 dnn;
     if (fabsf(normal.x) < PT_SQRT_OF_ONE_THIRD) dnn = mk(1.0f, 0.0f, 0.0f);

@@ -1,0 +1,371 @@
+// pt_k_path.hip -- `ordering = 2`, <= 32 primitives: whole paths on the typed work queues, ONE launch per group of
+// iterations (what bench.py, the adaptor and ptrender run).  Description next to PathArgs in pt_kernels.hpp.
+#include "pt_kernels.hpp"
+
+namespace ptk {
+
+// MESH: the scene holds MESH primitives with triangles (they share the spheres' stack; the traversal needs registers the
+// common variant must not pay for)
+template <bool MESH>
+__global__ __launch_bounds__(kBlock, 4) void k_path_q(SegArgs a, PathArgs pa, const GeomRec *__restrict__ geoms,
+                                                      const MatRec *__restrict__ mats, QTables qt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t *ctrl = reinterpret_cast<uint32_t *>(smem);   // [1] emitted (block sum), [32..96] survivors per level
+    uint32_t *lsurv = ctrl + 32;
+    if (threadIdx.x < 2) ctrl[threadIdx.x] = 0u;
+    if (threadIdx.x < 65) lsurv[threadIdx.x] = 0u;
+    uint32_t *park = ctrl + 18;
+    if (threadIdx.x == 0) {
+        const unsigned long long pl = (unsigned long long)(uintptr_t)(a.batch > 1u ? a.planes : a.image), st = (unsigned long long)a.plane_stride;
+        park[0] = (uint32_t)pl; park[1] = (uint32_t)(pl >> 32); park[2] = (uint32_t)st; park[3] = (uint32_t)(st >> 32);
+        park[4] = (uint32_t)a.cam.W; park[5] = (uint32_t)a.cam.row_offset; park[6] = a.cam.mW; park[7] = a.cam.shW;
+        park[8] = a.cam.mS; park[9] = a.cam.shS;
+    }
+    GeomRec *lg;
+    MatRec *lm;
+    FaceFrame *lf = reinterpret_cast<FaceFrame *>(smem + q_frames_offset(a.G, a.M));
+    CullRec *lc = reinterpret_cast<CullRec *>(smem + q_cull_offset(a.G, a.M));
+    {
+        uint32_t *fd = reinterpret_cast<uint32_t *>(lf);
+        const uint32_t *fs = reinterpret_cast<const uint32_t *>(qt.frames);
+        for (uint32_t i = threadIdx.x; i < (uint32_t)a.G * 3u * (uint32_t)(sizeof(FaceFrame) / 4); i += blockDim.x) fd[i] = fs[i];
+        uint32_t *cd = reinterpret_cast<uint32_t *>(lc);
+        const uint32_t *cs = reinterpret_cast<const uint32_t *>(qt.cull);
+        for (uint32_t i = threadIdx.x; i < (uint32_t)(qt.nbox + qt.nsph) * (uint32_t)(sizeof(CullRec) / 4); i += blockDim.x) cd[i] = cs[i];
+    }
+    stage_tables(smem, geoms, a.G, mats, a.M, true, lg, lm);        // ends with __syncthreads()
+
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
+    const uint32_t wslot = blockIdx.x * kWaves + wave;
+    const uint32_t D = pa.depth;
+    float *q = reinterpret_cast<float *>(smem + p_queue_offset(a.G, a.M)) + (size_t)wave * kPCap * kPFields;
+    // the wave's stack: field f of slot s at woff + f * kStack + s
+    const uint32_t wave_floats = kSFields * kStack;
+    const bool ub = pa.arena_bytes != 0u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pa.arena, 0, pa.arena_bytes, 0x00020000);
+    const uint32_t woff = wslot * wave_floats;             // in floats (buffer path: arena below 4 GiB)
+    auto ring_ld = [&](uint32_t off, uint32_t f) -> float {         // off = float index of field 0 of the slot
+        return ub ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off * 4u, f * kStack * 4u, 0)) : pa.arena[(size_t)off + f * kStack];
+    };
+    auto ring_st = [&](uint32_t off, uint32_t f, float v) {
+        if (ub) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, off * 4u, f * kStack * 4u, 0);
+        else pa.arena[(size_t)off + f * kStack] = v;
+    };
+
+    uint32_t *bank = a.bank ? a.sync->counts_b : a.sync->counts;
+    if (blockIdx.x == 0 && threadIdx.x < 72) {
+        uint32_t *other = a.bank ? a.sync->counts : a.sync->counts_b;
+        a.sync->totals[threadIdx.x] += other[threadIdx.x];
+        other[threadIdx.x] = 0u;
+        if (threadIdx.x == 0) bank[0] = a.n_rays;
+    }
+    uint32_t boxbits = 0u, meshbits = 0u;
+    for (int j = 0; j < a.G; ++j) {
+        if (lg[j].type == 1) boxbits |= 1u << j;
+        else if (MESH && lg[j].type == 2 && lg[j].inside_hits != 0) meshbits |= 1u << j;
+    }
+    const uint32_t aabbbits = boxbits | meshbits;         // primitives whose conservative bound is a box
+
+    uint32_t emitted = 0u;
+    uint32_t nbox = 0u, nsph = 0u;
+    uint32_t sp = 0u;                                      // rays on the wave's stack
+    uint32_t jobpos = 0u, jobend = 0u;
+    bool tickets_left = true;
+    // the ticket of the NEXT job is requested one job ahead (lane 0 holds it): its latency passes under the current job
+    uint32_t next_ticket = 0u;
+    uint32_t round = 0u;                                   // static jobs taken so far
+    const uint32_t nwaves = gridDim.x * kWaves;
+    uint32_t ctr = wslot % kTicketCtrs, dry = 0u;          // the counter this wave draws from; counters found exhausted in a row
+    if (pa.static_rounds == 0u && lane == 0) next_ticket = atomicAdd(pa.ticket + ctr * kTicketStride, 1u);
+    uint32_t turns = 0u;
+    const float kInf = 100000000000000000.0f;
+
+    for (;;) {
+        if (++turns > pa.turn_limit) { if (lane == 0) *pa.error = 3u; break; }                // never reached; bounds a broken build
+        int act;
+        if (nbox >= 64u) act = 1;
+        else if (nsph >= 64u) act = 2;
+        else if (nbox + nsph <= kPCap - 64u) {
+            if (sp >= 64u) act = 0;
+            else {
+                while (jobpos >= jobend && tickets_left) {                                 // next job of camera rays (a dry counter: try the next)
+                    unsigned long long job;
+                    if (round < pa.static_rounds) {
+                        job = (unsigned long long)wslot * pa.static_rounds + round;       // the wave's own contiguous range: neighbouring rays take similar paths
+                        round++;
+                        if (round == pa.static_rounds && lane == 0) next_ticket = atomicAdd(pa.ticket + ctr * kTicketStride, 1u);      // first drawn job, one job ahead
+                    } else {
+                        job = (unsigned long long)pa.static_rounds * nwaves + (unsigned long long)__builtin_amdgcn_readfirstlane(next_ticket) * kTicketCtrs + ctr;
+                        if (job * pa.job_rays >= (unsigned long long)a.n_rays) {          // this counter is dry: on to the next one
+                            dry++;
+                            ctr = ctr + 1u == kTicketCtrs ? 0u : ctr + 1u;
+                            if (dry >= kTicketCtrs) tickets_left = false;
+                        } else dry = 0u;
+                        if (tickets_left && lane == 0) next_ticket = atomicAdd(pa.ticket + ctr * kTicketStride, 1u);
+                    }
+                    const unsigned long long first = job * pa.job_rays;
+                    if (first < (unsigned long long)a.n_rays) { jobpos = (uint32_t)first; jobend = a.n_rays - jobpos < pa.job_rays ? a.n_rays : jobpos + pa.job_rays; }
+                }
+                if (jobpos < jobend) act = 3;
+                else if (sp) act = 0;
+                else if (nbox + nsph) act = nbox >= nsph ? 1 : 2;
+                else break;
+            }
+        } else act = nbox >= nsph ? 1 : 2;
+
+        if (act == 0 || act == 3) {
+            // ---------------------------------------------------------------- FRESH
+            f3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(1.0f, 1.0f, 1.0f);
+            uint32_t pv = 0u, level = 0u;
+            bool valid;
+            if (act == 3) {                                                                // camera rays
+                const uint32_t ray = jobpos + lane;
+                valid = ray < jobend;
+                jobpos = jobpos + 64u < jobend ? jobpos + 64u : jobend;
+                if (valid) {
+                    const uint32_t slot = a.batch > 1u ? ray / a.n_own : 0u;
+                    const uint32_t local = ray - slot * a.n_own;
+                    const uint32_t W = (uint32_t)a.cam.W;
+                    const uint32_t lr = local / W, x = local - lr * W;
+                    const uint32_t pixel = (lr * (uint32_t)a.cam.row_stride + (uint32_t)a.cam.row_offset) * W + x;
+                    camera_ray(a.cam, pixel, a.iteration + slot, o, d);
+                    pv = pixel | (slot << 24);
+                }
+            } else {                                                                       // the top of the wave's stack
+                const uint32_t cnt = sp < 64u ? sp : 64u;
+                valid = lane < cnt;
+                sp -= cnt;
+                const uint32_t off = woff + sp + lane;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // the wave's own stack stores have landed (vmcnt 0) ...
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");        // ... before they are read back through the same L1
+                if (valid) {
+                    o = mk(ring_ld(off, 0), ring_ld(off, 1), ring_ld(off, 2));
+                    d = mk(ring_ld(off, 3), ring_ld(off, 4), ring_ld(off, 5));
+                    thr = mk(ring_ld(off, 6), ring_ld(off, 7), ring_ld(off, 8));
+                    pv = __float_as_uint(ring_ld(off, 9));
+                    level = __float_as_uint(ring_ld(off, 10));
+                }
+            }
+            const CullRay cr = make_cull_ray(o, d);
+            float near_t = 3.0e38f;
+            uint32_t mask = 0u, next_j = 0u;
+#pragma unroll 2
+            for (int i = 0; i < qt.nbox; ++i) {
+                const CullRec r = lc[i];
+                float tn;
+                const bool keep = cull_box(r.a, r.b, cr, tn);
+                mask |= keep ? __float_as_uint(r.b[3]) : 0u;
+                const bool nearer = keep && tn < near_t;
+                near_t = nearer ? tn : near_t;
+                next_j = nearer ? __float_as_uint(r.a[3]) : next_j;
+            }
+#pragma unroll 2
+            for (int i = qt.nbox; i < qt.nbox + qt.nsph; ++i) {
+                const CullRec r = lc[i];
+                float tn;
+                const bool keep = cull_sphere(r.a, r.b, cr, tn);
+                mask |= keep ? __float_as_uint(r.b[1]) : 0u;
+                const bool nearer = keep && tn < near_t;
+                near_t = nearer ? tn : near_t;
+                next_j = nearer ? __float_as_uint(r.b[0]) : next_j;
+            }
+            if (!valid) mask = 0u;
+            const bool push = mask != 0u;
+#ifdef PT_CULL_STATS
+            qstat(8, 1ull); qstat(9, (unsigned long long)__popcll(__ballot(valid)));
+            atomicAdd(&g_cull_stats[5], (unsigned long long)__popc(mask));
+            if (act == 3) qstat(6, 1ull);
+#endif
+            mask &= ~(1u << next_j);
+            const bool tobox = push && ((boxbits >> next_j) & 1u);
+            const u64 bb = __ballot(tobox), sb = __ballot(push && !tobox);
+            if (bb | sb) {
+                if (push) {
+                    const uint32_t pos = tobox ? nbox + wave_rank(bb) : kPCap - 1u - (nsph + wave_rank(sb));
+                    float *r = q + pos;
+                    r[0 * kPCap] = o.x; r[1 * kPCap] = o.y; r[2 * kPCap] = o.z;
+                    r[3 * kPCap] = d.x; r[4 * kPCap] = d.y; r[5 * kPCap] = d.z;
+                    r[6 * kPCap] = thr.x; r[7 * kPCap] = thr.y; r[8 * kPCap] = thr.z;
+                    r[9 * kPCap] = __uint_as_float(pv);
+                    r[10 * kPCap] = __uint_as_float(mask);
+                    r[11 * kPCap] = __uint_as_float(next_j | (level << 8));
+                }
+                nbox += (uint32_t)__popcll(bb);
+                nsph += (uint32_t)__popcll(sb);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            continue;
+        }
+
+        // -------------------------------------------------------------------- TEST (one type per group, any levels)
+        const bool isb = act == 1;
+        const uint32_t have = isb ? nbox : nsph;
+        const uint32_t cnt = have < 64u ? have : 64u;
+        const bool valid = lane < cnt;
+        const uint32_t pos = isb ? (have - cnt + lane) : (kPCap - 1u - (have - cnt + lane));
+        if (isb) nbox -= cnt; else nsph -= cnt;
+#ifdef PT_CULL_STATS
+        qstat(isb ? 10 : 12, 1ull); qstat(isb ? 11 : 13, (unsigned long long)cnt);
+#endif
+        f3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(0, 0, 0);
+        uint32_t pv = 0u, mask = 0u, level = 0u;
+        int j = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (valid) {
+            const float *r = q + pos;
+            o = mk(r[0 * kPCap], r[1 * kPCap], r[2 * kPCap]);
+            d = mk(r[3 * kPCap], r[4 * kPCap], r[5 * kPCap]);
+            thr = mk(r[6 * kPCap], r[7 * kPCap], r[8 * kPCap]);
+            pv = __float_as_uint(r[9 * kPCap]);
+            mask = __float_as_uint(r[10 * kPCap]);
+            const uint32_t jl = __float_as_uint(r[11 * kPCap]);
+            j = (int)(jl & 0xFFu);
+            level = jl >> 8;
+        }
+        __builtin_amdgcn_wave_barrier();
+        float best;
+        int hit, face = -1;
+        f3 P = mk(0, 0, 0), N = mk(0, 0, 0);
+        {
+            const GeomRec *gr = lg + j;
+            float depth = -1.0f;
+            const bool jm = MESH && ((meshbits >> j) & 1u);
+            if (isb) { if (valid) depth = box_test_face(gr->inv, gr->xf, gr->inside_hits, o, d, P, face); }
+            else {
+                if (!MESH || __any(valid && !jm)) { if (valid && !jm) depth = sphere_test(gr->inv, gr->xf, o, d, P, N); }
+                if (MESH) { if (__any(valid && jm)) { if (valid && jm) depth = mesh_test(gr, o, d, P, N); } }
+            }
+            const bool wins = valid && depth > -PT_EPSILON && depth < kInf;
+            best = wins ? depth : kInf;
+            hit = wins ? j : -1;
+        }
+        if (__any(valid && mask != 0u)) {
+            bool active = valid;
+            for (;;) {
+                int next_j = -1;
+                if (active && mask != 0u) {
+                    const CullRay cr = make_cull_ray(o, d);
+                    float nt = 3.0e38f;
+                    uint32_t m = mask;
+                    while (m) {
+                        const int jj = __builtin_ctz(m);
+                        m &= m - 1u;
+                        const GeomRec *gb = lg + jj;
+                        float tn;
+                        if ((aabbbits >> jj) & 1u) (void)cull_box(gb->bmin, gb->bmax, cr, tn);
+                        else (void)cull_sphere(gb->bmin, gb->bmax, cr, tn);
+                        if (hit >= 0 && tn - gb->slack > best) { mask &= ~(1u << jj); continue; }
+                        if (tn < nt) { nt = tn; next_j = jj; }
+                    }
+                }
+                active = next_j >= 0;
+                if (!__any(active)) break;
+                if (active) { j = next_j; mask &= ~(1u << next_j); }
+                const bool jb = (boxbits >> j) & 1u;
+                const bool jm = MESH && ((meshbits >> j) & 1u);
+                const GeomRec *gr = lg + j;
+                f3 p = mk(0, 0, 0), nn = mk(0, 0, 0);
+                int fc = -1;
+                float depth = -1.0f;
+                if (__any(active && jb)) { if (active && jb) depth = box_test_face(gr->inv, gr->xf, gr->inside_hits, o, d, p, fc); }
+                if (__any(active && !jb && !jm)) { if (active && !jb && !jm) depth = sphere_test(gr->inv, gr->xf, o, d, p, nn); }
+                if (MESH) { if (__any(active && jm)) { if (active && jm) depth = mesh_test(gr, o, d, p, nn); } }
+                const bool wins = active && depth > -PT_EPSILON && (depth < best || (depth == best && j < hit));
+                if (wins) { best = depth; hit = j; P = p; N = nn; face = fc; }
+            }
+        }
+#ifdef PT_CULL_STATS
+        qstat(14, (unsigned long long)__popcll(__ballot(hit >= 0)));
+        qstat(7, (unsigned long long)__popcll(__ballot(hit >= 0 && level + 1u >= D)));
+#endif
+        // shade the hits (the ray's own level is its bounce index)
+        bool alive = false;
+        if (hit >= 0) {
+            const uint32_t slot = a.batch > 1u ? pv >> 24 : 0u, pixel = pv & a.pix_mask;
+            const MatRec m = lm[lg[hit].mat];
+            if (level + 1u >= D && !(m.emittance > 0.0f)) {
+                alive = true;                                         // depth exhausted: alive, contributes 0
+            } else {
+                const uint32_t iteration = a.iteration + slot;
+                uint32_t st = lcg_seed(stream_seed(pixel, iteration, 1u + level));
+                st = lcg_next(st); const float u_sel = u01(st);
+                st = lcg_next(st); const float xi1 = u01(st);
+                st = lcg_next(st); const float xi2 = u01(st);
+                f3 L = mk(0.0f, 0.0f, 0.0f);
+                int code = 4;
+                const bool hb = (boxbits >> hit) & 1u;
+                if (__any(hb)) { if (hb) code = scatter_box(m, P, face, lf + 3 * hit, u_sel, xi1, xi2, o, d, thr, L); }
+                if (__any(!hb)) { if (!hb) code = scatter(m, P, N, u_sel, xi1, xi2, o, d, thr, L); }
+                if (code == 3) {
+                    float *base = reinterpret_cast<float *>((uintptr_t)((unsigned long long)park[0] | ((unsigned long long)park[1] << 32)));
+                    size_t off = (size_t)pixel * 3;
+                    if (a.batch > 1u) {
+                        const uint32_t W = park[4];
+                        const uint32_t y = (uint32_t)(((unsigned long long)pixel * park[6]) >> park[7]);
+                        const uint32_t x = pixel - y * W;
+                        const uint32_t ly = (uint32_t)(((unsigned long long)(y - park[5]) * park[8]) >> park[9]);
+                        off = (size_t)slot * (size_t)((unsigned long long)park[2] | ((unsigned long long)park[3] << 32)) + (size_t)(ly * W + x) * 3;
+                    }
+                    float *px = base + off;
+                    (void)unsafeAtomicAdd(px, L.x); (void)unsafeAtomicAdd(px + 1, L.y); (void)unsafeAtomicAdd(px + 2, L.z);
+                    emitted++;
+                }
+                alive = code <= 2;
+            }
+        }
+        // survivors: counted per level (one LDS atomic for the group); those with bounces left go on the wave's stack
+        if (alive) atomicAdd(&lsurv[level + 1u], 1u);
+        const bool onward = alive && level + 1u < D;
+        const u64 ballot = __ballot(onward);
+        if (ballot) {
+            const uint32_t n = (uint32_t)__popcll(ballot);
+            if (sp + n > kStack) { if (lane == 0) *pa.error = 2u; }        // never: see the bound above
+            else {
+                if (onward) {
+                    const uint32_t off = woff + sp + wave_rank(ballot);
+                    ring_st(off, 0, o.x); ring_st(off, 1, o.y); ring_st(off, 2, o.z);
+                    ring_st(off, 3, d.x); ring_st(off, 4, d.y); ring_st(off, 5, d.z);
+                    ring_st(off, 6, thr.x); ring_st(off, 7, thr.y); ring_st(off, 8, thr.z);
+                    ring_st(off, 9, __uint_as_float(pv));
+                    ring_st(off, 10, __uint_as_float(level + 1u));
+                }
+                sp += n;
+            }
+        }
+    }
+
+    for (int sft = 32; sft > 0; sft >>= 1) emitted += __shfl_down(emitted, sft);
+    if (lane == 0 && emitted) atomicAdd(&ctrl[1], emitted);
+    __syncthreads();
+    if (threadIdx.x == 0 && ctrl[1]) atomicAdd(&a.sync->emitted, (u64)ctrl[1]);
+    if (threadIdx.x >= 1 && threadIdx.x < 65 && lsurv[threadIdx.x]) atomicAdd(&bank[threadIdx.x], lsurv[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------ host side ---------
+hipError_t path_setup(bool mesh, uint32_t lds_bytes, int *blocks_per_cu) {
+    const void *fn = mesh ? reinterpret_cast<const void *>(&k_path_q<true>) : reinterpret_cast<const void *>(&k_path_q<false>);
+    if (lds_bytes > 64u * 1024u) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, kBlock, lds_bytes) != hipSuccess || occ < 1) occ = 2;
+    *blocks_per_cu = occ;
+    return hipSuccess;
+}
+
+void path_launch(bool mesh, int grid, uint32_t lds, hipStream_t st, const SegArgs &a, const PathArgs &pa,
+                 const GeomRec *g, const MatRec *m, const QTables &qt) {
+    if (mesh) hipLaunchKernelGGL(k_path_q<true>, dim3(grid), dim3(kBlock), lds, st, a, pa, g, m, qt);
+    else hipLaunchKernelGGL(k_path_q<false>, dim3(grid), dim3(kBlock), lds, st, a, pa, g, m, qt);
+}
+
+#ifdef PT_CULL_STATS
+void cull_stats_path(unsigned long long *acc16) {
+    unsigned long long v[16];
+    if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_cull_stats), sizeof v) == hipSuccess) for (int i = 0; i < 16; ++i) acc16[i] += v[i];
+}
+#endif
+
+}  // namespace ptk

@@ -291,6 +291,7 @@ void pt_config_default(pt_config *cfg) {
     cfg->max_depth = 8;
     cfg->row_stride = 1;
     cfg->streams = 1;
+    cfg->path_static_eighths = 4;
 }
 
 int pt_build_transform(const float t[3], const float r[3], const float s[3], float xf[16], float inv[16]) {

@@ -161,6 +161,27 @@ class Scene:
     def material_array(self):
         return (Material * self.M)(*self.materials)
 
+    @classmethod
+    def from_product(cls, geoms, mats, cam, meshes=None):
+        """The product ABI's PODs (pt_geom: rows x,y,z only) -> an oracle scene (full 4x4 rows, w = (0,0,0,1))."""
+        og = []
+        for g in geoms:
+            o = Geom()
+            o.type, o.materialid = g.type, g.materialid
+            for k in range(12):
+                o.transform[k] = g.transform[k]
+                o.inverseTransform[k] = g.inverseTransform[k]
+            o.transform[15] = o.inverseTransform[15] = 1.0
+            og.append(o)
+        om = []
+        for m in mats:
+            x = Material()
+            C.memmove(C.byref(x), C.byref(m), 64)
+            om.append(x)
+        oc = Camera()
+        C.memmove(C.byref(oc), C.byref(cam), 52)
+        return cls(og, om, oc, meshes=meshes)
+
     def with_resolution(self, W, H):
         """Same scene at another resolution, fov recomputed the way scene.cpp:201-205 does."""
         import math

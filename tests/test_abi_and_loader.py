@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(pkg):
         assert hasattr(L, name), "libptmi355.so does not export %s" % name
     assert sorted(pkg.EXPORTS) == declared
     version = int(re.search(r"#define\s+PTMI355_ABI_VERSION\s+(\d+)", hdr).group(1))
-    assert pkg.lib().pt_abi_version() == version == 6
+    assert pkg.lib().pt_abi_version() == version == 7
 
 
 def test_pod_sizes_match_reference_structs(pkg):
@@ -48,6 +48,26 @@ def test_no_cpu_fallback(pkg):
         pkg.PathTracer()
     assert "no HIP device" in str(e.value)
     assert pkg.lib().pt_render(None, 1, 1) != 0
+
+
+def test_options_retired_in_abi7_are_refused_before_any_device_is_touched(pkg):
+    """geometry_path=1, the look-back scan (compaction=1) and merge_floor were measured losers and left the launch
+    matrix in ABI 7: the fields stay (layout), non-zero values are an argument error -- with or without a GPU."""
+    import ctypes as C
+    for kw in (dict(geometry_path=1), dict(compaction=1), dict(merge_floor=4), dict(path_static_eighths=9), dict(cluster_size=99)):
+        cfg = pkg.default_config(**kw)
+        h = C.c_void_p()
+        assert pkg.lib().pt_create(C.byref(cfg), C.byref(h)) == -3, kw          # PT_ERR_ARGUMENT
+        assert not h.value
+    assert pkg.default_config().path_static_eighths == 4
+
+
+def test_library_reads_no_environment_switches():
+    """Behaviour switches travel in pt_config (ABI 7), not in the process environment (the adaptor's PT_* variables are
+    the reference API's missing option channel and live in adaptor/ only)."""
+    csrc = os.path.join(ROOT, "project2-pathtracer_amd", "csrc")
+    for f in os.listdir(csrc):
+        assert "getenv" not in open(os.path.join(csrc, f), errors="replace").read(), f
 
 
 def test_product_tree_never_references_the_oracle():

@@ -221,7 +221,7 @@ def test_gpu_row_shards_sum_to_the_full_frame(pt):
 @pytest.mark.gpu
 def test_gpu_rejects_unsupported_combinations(pt):
     sc = orc.load_golden_scene("sampleScene").with_resolution(64, 48)
-    for kw in (dict(compaction=1), dict(culling=1), dict(geometry_path=1)):
+    for kw in (dict(culling=1),):
         cfg = pt.default_config(max_depth=4, direct_light=1, **kw)
         tr = pt.PathTracer(cfg)
         with pytest.raises(pt.PtError, match="direct_light"):

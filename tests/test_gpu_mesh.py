@@ -40,8 +40,8 @@ def test_mesh_primary_hits_match_brute_force(pt, mesh_scene):
                 assert np.array_equal(np.array(list(PP), np.float32), P[idx]) and np.array_equal(np.array(list(NN), np.float32), N[idx])
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(culling=1), dict(geometry_path=1), dict(compaction=1), dict(batch=2, chunk_rays=100),
-                                dict(streams=2), dict(ordering=1), dict(ordering=1, batch=2, streams=2), dict(ordering=2), dict(direct_light=1), dict(culling=1, geometry_path=1)])
+@pytest.mark.parametrize("kw", [dict(), dict(culling=1), dict(batch=2, chunk_rays=100),
+                                dict(streams=2), dict(ordering=1), dict(ordering=1, batch=2, streams=2), dict(ordering=2), dict(direct_light=1)])
 def test_mesh_scene_matches_oracle(pt, mesh_scene, kw):
     """mirror torus, glass tetrahedron (rays start inside it), diffuse icosphere, next to a sphere and a rotated cube"""
     depth, iters = 6, 3

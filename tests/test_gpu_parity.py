@@ -189,9 +189,9 @@ def test_accumulation_continues_from_host_image(pt, cornell200):
     assert np.array_equal(a, want)
 
 
-@pytest.mark.parametrize("kw", [dict(geometry_path=1), dict(chunk_rays=64), dict(batch=1), dict(batch=2), dict(batch=3, chunk_rays=100), dict(chunk_rays=64, merge_floor=3000), dict(chunk_rays=64, merge_floor=50, batch=2), dict(chunk_rays=1000), dict(chunk_rays=16, merge_floor=1), dict(chunk_rays=100, merge_floor=7), dict(blocks_per_cu=1),
-                                dict(culling=1), dict(culling=1, geometry_path=1), dict(ordering=1), dict(ordering=1, batch=2), dict(ordering=1, chunk_rays=100, merge_floor=7), dict(ordering=1, batch=1, chunk_rays=64), dict(ordering=1, chunk_rays=128, blocks_per_cu=1), dict(ordering=1, batch=5, blocks_per_cu=2), dict(ordering=2), dict(ordering=2, batch=2), dict(ordering=2, batch=1, chunk_rays=64), dict(ordering=2, chunk_rays=192, blocks_per_cu=1), dict(ordering=2, batch=5, blocks_per_cu=2),
-                                dict(compaction=1), dict(compaction=1, chunk_rays=256), dict(compaction=1, chunk_rays=1024, geometry_path=1)])
+@pytest.mark.parametrize("kw", [dict(chunk_rays=64), dict(batch=1), dict(batch=2), dict(batch=3, chunk_rays=100), dict(chunk_rays=1000), dict(chunk_rays=16), dict(blocks_per_cu=1),
+                                dict(culling=1), dict(ordering=1), dict(ordering=1, batch=2), dict(ordering=1, batch=1, chunk_rays=64), dict(ordering=1, chunk_rays=128, blocks_per_cu=1), dict(ordering=1, batch=5, blocks_per_cu=2),
+                                dict(ordering=2), dict(ordering=2, batch=2), dict(ordering=2, batch=1, chunk_rays=64), dict(ordering=2, chunk_rays=192, blocks_per_cu=1), dict(ordering=2, batch=5, blocks_per_cu=2)])
 def test_launch_variants_are_bit_identical(pt, cornell200, kw):
     ref = make_tracer(cornell200)
     ref.set_image(None); ref.render(1, 3)
@@ -370,8 +370,10 @@ def test_full_size_properties_1080p(pt):
     assert np.array_equal(got[rows], a[rows])
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(batch=2, chunk_rays=100), dict(geometry_path=1), dict(culling=1), dict(streams=2), dict(direct_light=1),
-                                dict(ordering=1), dict(ordering=1, batch=3, chunk_rays=128), dict(ordering=1, streams=2), dict(ordering=2)])
+@pytest.mark.parametrize("kw", [dict(), dict(batch=2, chunk_rays=100), dict(culling=1), dict(streams=2), dict(direct_light=1),
+                                dict(ordering=1), dict(ordering=1, batch=3, chunk_rays=128), dict(ordering=1, streams=2),
+                                dict(ordering=2), dict(ordering=2, batch=3, chunk_rays=128), dict(ordering=2, streams=2), dict(ordering=2, wide_variant=1), dict(ordering=2, wide_variant=2),
+                                dict(ordering=2, cluster_size=4), dict(ordering=2, cluster_size=16), dict(ordering=2, path_static_eighths=0), dict(ordering=2, path_static_eighths=8, batch=1)])
 def test_many_primitives_scene_matches_oracle(pt, kw):
     """BASELINE config 4's scene (256 spheres+cubes incl. rotated cubes, mirrors, glass): the two-level
     candidate culling must never change the nearest hit."""
@@ -439,12 +441,14 @@ def test_config4_and_config5_full_size_slices(pt):
     want, _ = orc.render(c4, oracle_config(8, **sh_cfg), 1, 1)
     rows = np.arange(1080) % 270 == 11
     assert np.array_equal(full[rows], want[rows])
-    # what bench.py --workload c4 times: the many-primitive typed work queues, two contexts, batched
-    trq = make_tracer(c4, ordering=1, streams=2)
-    trq.set_image(None); trq.render(1, 1)
-    stq = trq.stats()
-    assert np.array_equal(trq.image(), full) and [stq.live[k] for k in range(9)] == [st.live[k] for k in range(9)]
-    trq.close()
+    # what bench.py --workload c4 times: the whole-path kernel for 33..256 primitives (k_path_w), two contexts
+    for kwq in (dict(ordering=2, streams=2), dict(ordering=2, wide_variant=1), dict(ordering=1, streams=2)):
+        trq = make_tracer(c4, **kwq)
+        trq.set_image(None); trq.render(1, 1)
+        stq = trq.stats()
+        assert np.array_equal(trq.image(), full) and [stq.live[k] for k in range(9)] == [st.live[k] for k in range(9)], kwq
+        assert stq.emitted == st.emitted
+        trq.close()
     n, arrs, pix = tr.trace_pool(1, 3)
     assert np.all(np.diff(pix.astype(np.int64)) > 0)
 
@@ -489,7 +493,7 @@ def _scaled_scene(name, factor, w, h):
 
 
 @pytest.mark.parametrize("factor", [0.05, 1.0, 37.0, 1000.0])
-@pytest.mark.parametrize("name,ordering", [("sampleScene", 0), ("random256", 0), ("random256", 1)])
+@pytest.mark.parametrize("name,ordering", [("sampleScene", 0), ("random256", 0), ("random256", 1), ("random256", 2)])
 def test_culling_is_conservative_at_other_scene_scales(pt, name, ordering, factor):
     """The culling margins are absolute + relative; RAY_BIAS / the sphere pull-back are absolute in the
     reference's own spec.  Whatever that does to the picture at odd scales, the culled nearest hit

@@ -119,8 +119,10 @@ def test_bench_two_ranks_started_plainly_gloo_rehearsal(pt):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     env["PT_BENCH_BACKEND"] = "gloo"
+    dump = os.path.join(root, "gpurun_out", "rehearsal_frame.npy")
+    os.makedirs(os.path.dirname(dump), exist_ok=True)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--repeats", "2",
-                        "--no-cpu-baseline", "--resolution", "640x360"], env=env, capture_output=True, text=True, timeout=600)
+                        "--no-cpu-baseline", "--resolution", "640x360", "--dump-image", dump], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
@@ -133,6 +135,13 @@ def test_bench_two_ranks_started_plainly_gloo_rehearsal(pt):
     ex = res["exchange"]
     assert ex["ms"] > 0 and ex["k_steps_only_ms"] > 0 and ex["value_if_exchanged_every_pass"] < res["value"]
     assert res["ms_per_step"] * 4 == pytest.approx(ex["k_steps_only_ms"] + ex["share_charged_to_value_ms"], rel=1e-3)
+    # both accountings at the top level
+    assert res["value_if_exchanged_every_pass"] == ex["value_if_exchanged_every_pass"] and "exchange_accounting" in res
+    # the frame rank 0 holds after the exchange = the HIP path under two processes: bit-identical to the oracle (iterations 3..6)
+    got = np.load(dump)
+    sc = orc.load_golden_scene("cornell_mirror").with_resolution(640, 360)
+    want, _ = orc.render(sc, oracle_config(8), 3, 4)
+    assert got.shape == want.shape and np.array_equal(got, want)
 
 
 def _subset_scene(name, keep, w, h):
@@ -216,7 +225,8 @@ def _stacked_scene(w, h):
     return orc.Scene(geoms, base.materials, cam)
 
 
-@pytest.mark.parametrize("kw", [dict(ordering=0), dict(ordering=1), dict(ordering=1, streams=2, batch=2)])
+@pytest.mark.parametrize("kw", [dict(ordering=0), dict(ordering=1), dict(ordering=1, streams=2, batch=2), dict(ordering=2), dict(ordering=2, streams=2, batch=2),
+                                dict(ordering=2, wide_variant=2, cluster_size=3)])
 def test_many_primitive_kernels_when_the_candidate_list_overflows(pt, kw):
     """The many-primitive kernels keep at most 8 candidates per ray in registers; a ray with more takes the reference's
     brute-force loop.  Here nearly every ray does."""
@@ -248,25 +258,21 @@ def test_fold_of_batched_iterations_at_odd_widths(pt, w, h):
         tr.close()
 
 
-@pytest.mark.parametrize("eighths", ["0", "8", "3"])
+@pytest.mark.parametrize("eighths", [0, 8, 3])
 def test_whole_path_kernel_job_hand_out_all_drawn_all_static_and_mixed(pt, eighths):
     """ordering = 2: the jobs of camera rays are partly the waves' own contiguous ranges, partly drawn from sixteen ticket
-    counters (PT_P_STATIC_EIGHTHS, read at upload).  Whatever the split -- all drawn, all static but the remainder, mixed --
+    counters (pt_config.path_static_eighths).  Whatever the split -- all drawn, all static but the remainder, mixed --
     every camera ray is rendered exactly once: image and live counts are the oracle's."""
     sc = orc.load_golden_scene("cornell_mirror").with_resolution(213, 117)
-    os.environ["PT_P_STATIC_EIGHTHS"] = eighths
-    try:
-        for kw in (dict(ordering=2, batch=4), dict(ordering=2, streams=2, batch=3, chunk_rays=64), dict(ordering=2, batch=1, blocks_per_cu=1)):
-            tr = make_tracer(sc, depth=6, **kw)
-            tr.set_image(None)
-            tr.render(1, 7)
-            want, live = orc.render(sc, oracle_config(6), 1, 7)
-            st = tr.stats()
-            assert [st.live[k] for k in range(7)] == [int(v) for v in live], (eighths, kw)
-            assert np.array_equal(tr.image(), want), (eighths, kw)
-            tr.close()
-    finally:
-        del os.environ["PT_P_STATIC_EIGHTHS"]
+    for kw in (dict(ordering=2, batch=4), dict(ordering=2, streams=2, batch=3, chunk_rays=64), dict(ordering=2, batch=1, blocks_per_cu=1)):
+        tr = make_tracer(sc, depth=6, path_static_eighths=eighths, **kw)
+        tr.set_image(None)
+        tr.render(1, 7)
+        want, live = orc.render(sc, oracle_config(6), 1, 7)
+        st = tr.stats()
+        assert [st.live[k] for k in range(7)] == [int(v) for v in live], (eighths, kw)
+        assert np.array_equal(tr.image(), want), (eighths, kw)
+        tr.close()
 
 
 def test_whole_path_kernel_equals_the_stable_kernel_on_full_frames(pt):

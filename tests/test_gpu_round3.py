@@ -1,0 +1,158 @@
+"""-m gpu: round-3 additions -- the whole-path kernel for 33..256 primitives (k_path_w), the device-side guards of the
+whole-path kernels surfaced through pt_sync, the roofline block of the bench line, and the MESH bench workloads.
+Same bar as tests/test_gpu_parity.py: bit-exact (numpy == on float32)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import orc
+from gpu_common import make_tracer, oracle_config, to_product
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _subset(name, keep, w, h):
+    base = orc.load_golden_scene(name).with_resolution(w, h)
+    return orc.Scene([base.geoms[i] for i in keep], base.materials, base.camera)
+
+
+@pytest.mark.parametrize("label,keep", [
+    ("33 primitives: the smallest scene the kernel takes", list(range(33))),
+    ("cubes only (no sphere cluster at all)", [i for i in range(256) if i < 6 or i % 2 == 1][:100]),
+    ("spheres only, no enclosing room: most rays leave without a candidate", [i for i in range(6, 256) if i % 2 == 0][:90]),
+    ("all 256", list(range(256))),
+])
+@pytest.mark.parametrize("kw", [dict(), dict(wide_variant=1, batch=3), dict(wide_variant=2, streams=2), dict(cluster_size=5, chunk_rays=64)])
+def test_whole_path_wide_kernel_on_subsets_of_config4(pt, label, keep, kw):
+    """k_path_w (ordering = 2, 33..256 analytic primitives) against the oracle: image, live counts, emitter hits; and
+    against the stable kernel's ray pool of the same context (the parity hook runs the per-bounce WIDE kernel)."""
+    sc = _subset("random256", keep, 200, 112)
+    depth, iters = 8, 3
+    tr = make_tracer(sc, depth=depth, ordering=2, **kw)
+    tr.set_image(None)
+    tr.render(1, iters)
+    want, live = orc.render(sc, oracle_config(depth), 1, iters)
+    st = tr.stats()
+    assert [st.live[k] for k in range(depth + 1)] == [int(v) for v in live], label
+    assert np.array_equal(tr.image(), want), label
+    if kw.get("streams", 1) == 1:
+        n, arrs, pix = tr.trace_pool(2, 3)
+        on, oarrs, opix = orc.trace_pool(sc, oracle_config(depth), 2, 3)
+        assert n == on and np.array_equal(pix, opix) and all(np.array_equal(a, b) for a, b in zip(arrs, oarrs))
+    tr.close()
+
+
+def test_whole_path_wide_kernel_continues_a_host_image_and_long_groups(pt):
+    """accumulation continues from an uploaded image; a 40-iteration launch group uses every slot bit"""
+    sc = orc.load_golden_scene("random256").with_resolution(96, 54)
+    want, _ = orc.render(sc, oracle_config(8), 1, 44)
+    part, _ = orc.render(sc, oracle_config(8), 1, 4)
+    tr = make_tracer(sc, depth=8, ordering=2)
+    tr.set_image(part)
+    tr.render(5, 40)
+    assert np.array_equal(tr.image(), want)
+    tr.close()
+
+
+@pytest.mark.parametrize("name,kw", [("cornell_mirror", dict()), ("random256", dict()), ("random256", dict(wide_variant=2))])
+def test_turn_limit_guard_surfaces_through_sync(pt, name, kw):
+    """The whole-path kernels bound the scheduling turns of a wave (a broken build must end, not hang the device).  With
+    the limit lowered to a few turns the guard trips: the launch ends at once and pt_sync reports PT_ERR_HIP."""
+    sc = orc.load_golden_scene(name).with_resolution(160, 90)
+    tr = make_tracer(sc, depth=8, ordering=2, **kw)
+    tr.set_image(None)
+    tr.set_turn_limit(3)
+    tr.render(1, 2)
+    with pytest.raises(pt.PtError, match="turn limit"):
+        tr.sync()
+    tr.close()
+    # an untouched context right afterwards renders correctly (the guard left the device usable)
+    tr = make_tracer(sc, depth=8, ordering=2, **kw)
+    tr.set_image(None)
+    tr.render(1, 2)
+    want, _ = orc.render(sc, oracle_config(8), 1, 2)
+    assert np.array_equal(tr.image(), want)
+    tr.close()
+
+
+def test_stack_overflow_guard_surfaces_through_sync(pt):
+    """A build whose per-wave stack of survivors is too small for the depth-first bound (-DPT_STACK_SLOTS=64 instead of
+    256: the bound is 63 + two pops of 64) must report 'a level ring overflowed' through pt_sync, not write past the
+    stack.  The variant is built here (hipcc is on the box) and loaded beside the shipped library."""
+    import ctypes as C
+    out = os.path.join(ROOT, "project2-pathtracer_amd", "build", "variants", "smallstack.so")
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "build_variant.sh"), "smallstack", "-DPT_STACK_SLOTS=64"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and os.path.exists(out), (r.stdout + r.stderr)[-2000:]
+    L = C.CDLL(out)
+    L.pt_last_error.restype = C.c_char_p
+    sc = orc.load_golden_scene("cornell_mirror").with_resolution(320, 180)
+    geoms, mats, cam = to_product(sc)
+    cfg = pt.default_config(max_depth=8, ordering=2)
+    h = C.c_void_p()
+    assert L.pt_create(C.byref(cfg), C.byref(h)) == 0
+    assert L.pt_upload_scene(h, geoms, len(geoms), mats, len(mats), C.byref(cam)) == 0
+    assert L.pt_set_image(h, None) == 0
+    assert L.pt_render(h, 1, 8) == 0
+    rc = L.pt_sync(h)
+    assert rc == -2 and b"overflowed" in L.pt_last_error(), (rc, L.pt_last_error())
+    L.pt_destroy(h)
+
+
+def test_bench_line_states_what_bounds_the_kernel(pt):
+    """The roofline block of bench.py's JSON line: `bound` is what the counters say, the survey-byte figure
+    is labelled as such, the PMC traffic is per STEP with the per-launch figure beside it, and every derived number is
+    consistent with the ones it is derived from."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "4", "--repeats", "3", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    roof = res["roofline"]
+    assert roof["bound"] in ("valu-issue", "hbm") and roof["stated_roofline"].startswith("hbm")
+    assert roof["frac"] == pytest.approx(roof["algorithmic_bytes_per_step"] / (res["ms_per_step"] * 1e-3) / 8e12, abs=1e-4)
+    assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], abs=1e-4)
+    assert roof["algorithmic_bytes_per_launch"] == pytest.approx(roof["algorithmic_bytes_per_step"] * res["steps"] / roof["launches"], rel=1e-6)
+    src = roof["traffic_source"]
+    assert src is not None and src["file"] == "profiles/traffic_latest.json"
+    if src["stale"]:
+        assert roof["traffic"] is None and roof["hbm_measured"] is None and roof["valu_issue"] is None
+    else:
+        hm, vi = roof["hbm_measured"], roof["valu_issue"]
+        assert roof["traffic"] == hm["bytes_per_step"]
+        assert roof["traffic_per_launch"] == pytest.approx(roof["traffic"] * res["steps"] / roof["launches"], rel=1e-6)
+        assert hm["GB_s"] == pytest.approx(hm["bytes_per_step"] / (res["ms_per_step"] * 1e-3) / 1e9, rel=2e-3)
+        assert hm["frac_of_peak"] == pytest.approx(hm["GB_s"] / 8000.0, abs=1e-4)
+        assert vi["frac"] == pytest.approx(vi["achieved_G_wave_inst_per_s"] / 1228.8, abs=1e-3) and "frac_of_4_cycle_issue" not in vi
+        lo, hi = vi["measured_ceiling_ns_per_wave_instruction_per_simd"]
+        assert vi["frac_of_measured_ceiling"] == [pytest.approx(lo / vi["ns_per_wave_instruction_per_simd"], abs=2e-3), pytest.approx(hi / vi["ns_per_wave_instruction_per_simd"], abs=2e-3)]
+        assert roof["bound"] == ("hbm" if hm["frac_of_peak"] > vi["frac"] else "valu-issue")
+
+
+@pytest.mark.parametrize("workload", ["mesh", "mesh5k"])
+def test_mesh_bench_workloads_render_what_the_oracle_renders(pt, workload):
+    """bench.py --workload mesh / mesh5k (scenes/cornell_mesh*.txt at 1920x1080 there): the same scene files through the
+    library's loader at a small resolution, against the oracle's brute-force triangle loop."""
+    sys.path.insert(0, ROOT)
+    import bench
+    path = os.path.join(ROOT, bench.WORKLOADS[workload][0])
+    sf = pt.SceneFile(path)
+    geoms, mats, cam = sf.flatten(0)
+    cam.resolution[0], cam.resolution[1] = 128.0, 96.0
+    meshes = sf.meshes()
+    assert meshes and (workload != "mesh5k" or len(meshes[0][2]) == 5120)
+    sc = orc.Scene.from_product(geoms, mats, cam, meshes)
+    for kw in (dict(ordering=2), dict(ordering=0)):
+        tr = pt.PathTracer(pt.default_config(max_depth=6, **kw))
+        tr.set_meshes(meshes)
+        tr.upload(geoms, mats, cam)
+        tr.set_image(None)
+        tr.render(1, 2)
+        want, live = orc.render(sc, oracle_config(6), 1, 2)
+        st = tr.stats()
+        assert [st.live[k] for k in range(7)] == [int(v) for v in live], kw
+        assert np.array_equal(tr.image(), want), kw
+        tr.close()

@@ -1,7 +1,7 @@
 """Exact-pass statistics of the culled nearest-hit (diagnostic): wave-level iterations of the per-lane
 cube / sphere loops and their active lanes.  Needs a library built with -DPT_CULL_STATS:
   cd project2-pathtracer_amd && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off \
-     -fhip-fp32-correctly-rounded-divide-sqrt -DPT_CULL_STATS -shared -o libptmi355_stats.so csrc/pt_kernels.hip csrc/pt_scene.cpp
+     (now: tools/build_variant.sh stats -DPT_CULL_STATS)
 (select it with PTMI355_LIB=.../build/variants/stats.so).
 Round-1 result on configs[2]: cube loop 1.43 iterations/group at 31 active lanes, sphere loop 0.96 at 6.1,
 0.78 candidates per ray."""

@@ -4,7 +4,7 @@
 # Build a variant with e.g.
 #   cd project2-pathtracer_amd && mkdir -p build/variants && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC \
 #     -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -fno-slp-vectorize -w -shared \
-#     csrc/pt_kernels.hip csrc/pt_scene.cpp <extra flags> -o build/variants/<tag>.so
+#     csrc/pt_*.hip csrc/pt_scene.cpp <extra flags> -o build/variants/<tag>.so
 # (build/ is git-ignored but travels to the GPU box with the snapshot); PTMI355_LIB selects the library.
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 for lib in "" $ROOT/project2-pathtracer_amd/build/variants/*.so; do

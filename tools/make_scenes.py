@@ -189,6 +189,15 @@ def mesh_scene(out):
         ("cube", 0, (-2.8, 6.5, -2.0), (25, 40, 10), (1.6, 1.6, 1.6)),
     ]
     write_scene(os.path.join(out, "cornell_mesh.txt"), mats, objs, (800, 600), 500, "renders/cornell_mesh.bmp", frames=1)
+    # one large mesh (bench.py --workload mesh5k): a 5 120-triangle icosphere, diffuse, beside a sphere and a cube
+    v, f = icosphere(4)
+    write_obj(os.path.join(out, "meshes", "icosphere5k.obj"), v, f)
+    objs5k = [o for o in CORNELL_OBJECTS[:5]] + [CORNELL_OBJECTS[8]] + [
+        ("meshes/icosphere5k.obj", 2, (-0.6, 3.2, 0.0), (20, 35, 0), (5.0, 5.0, 5.0)),
+        ("sphere", 4, (2.9, 7.0, 1.5), (0, 0, 0), (2, 2, 2)),
+        ("cube", 0, (-3.2, 7.0, -2.0), (25, 40, 10), (1.6, 1.6, 1.6)),
+    ]
+    write_scene(os.path.join(out, "cornell_mesh5k.txt"), mats, objs5k, (800, 600), 500, "renders/cornell_mesh5k.bmp", frames=1)
 
 
 def main():

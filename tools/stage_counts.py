@@ -1,8 +1,8 @@
 """Static instruction counts per marked stage (PT_MARK) of k_bounce_q<LAST=0,GEN=0,MESH=0> in a -DPT_MARKERS -save-temps build:
-   cd project2-pathtracer_amd/build/mark && hipcc --offload-arch=gfx950 <Makefile FLAGS> -DPT_MARKERS -save-temps -c ../../csrc/pt_kernels.hip -o m.o
+   cd project2-pathtracer_amd/build/mark && hipcc --offload-arch=gfx950 <Makefile FLAGS> -DPT_MARKERS -save-temps -c ../../csrc/pt_k_queue.hip -o m.o
 usage: python tools/stage_counts.py [file.s] [mangled-name substring]"""
 import re, sys
-path = sys.argv[1] if len(sys.argv) > 1 else "project2-pathtracer_amd/build/mark/pt_kernels-hip-amdgcn-amd-amdhsa-gfx950.s"
+path = sys.argv[1] if len(sys.argv) > 1 else "project2-pathtracer_amd/build/mark/pt_k_queue-hip-amdgcn-amd-amdhsa-gfx950.s"
 key = sys.argv[2] if len(sys.argv) > 2 else "k_bounce_qILb0ELb0ELb0EEE"
 s = open(path).read()
 m = re.search(r'^(_ZN[^\n:]*' + re.escape(key) + r'[^\n:]*):', s, re.M)
