@@ -708,10 +708,11 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         int csize = c->cfg.cluster_size > 0 ? c->cfg.cluster_size : (c->pathw ? PT_CLUSTER_PATHW : PT_CLUSTER);
         if (csize < 1) csize = 1;
         if (csize > kClusterMax) csize = kClusterMax;
-        for (; csize <= kClusterMax; ++csize) {                // the per-lane cluster mask has 64 bits
+        for (; csize <= kClusterMax; ++csize) {                // the per-lane cluster masks: 64 bits in all, 32 per type for k_path_w
             int nb = 0, ns = 0;
             for (int i = 0; i < G; ++i) { if (g[i].type == 1) nb++; else if (g[i].type == 0) ns++; }
-            if ((nb + csize - 1) / csize + (ns + csize - 1) / csize <= 64) break;
+            const int cb = (nb + csize - 1) / csize, cs = (ns + csize - 1) / csize;
+            if (cb + cs <= 64 && (!c->pathw || (cb <= 32 && cs <= 32))) break;
         }
         if (csize > kClusterMax) csize = kClusterMax;
         for (int pass = 0; pass < 2; ++pass) {
@@ -757,7 +758,8 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
                 if (pass == 0) c->nbc++; else c->nsc++;
             }
         }
-        if (c->nbc + c->nsc > 64) c->wide = false;            // the per-lane cluster mask has 64 bits
+        if (c->pathw && (c->nbc > 32 || c->nsc > 32)) c->pathw = false;
+        if (c->nbc + c->nsc > 64) { c->wide = false; c->pathw = false; }            // the per-lane cluster mask has 64 bits
         else {
             const size_t idbytes = (ids.size() + 15) & ~(size_t)15;
             cluster_blob.assign(recs.size() * sizeof(ClusterRec) + idbytes, 0);

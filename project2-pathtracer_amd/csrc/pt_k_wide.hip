@@ -93,6 +93,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, c
     const ClusterRec *cl = reinterpret_cast<const ClusterRec *>(lg + a.G);
     const int nbc = a.nbc, nsc = a.nsc;
     const unsigned char *members = reinterpret_cast<const unsigned char *>(cl + nbc + nsc);
+    const int nmem = nbc + nsc > 0 ? cl[nbc + nsc - 1].first + cl[nbc + nsc - 1].count : 0;      // analytic primitives (MESH objects without data are in no cluster)
 
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     const uint32_t wslot = blockIdx.x * WAVES + wave;
@@ -203,6 +204,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, c
                     level = __float_as_uint(ring_ld(off, 10));
                 }
             }
+#ifdef PT_CULL_STATS
+            qstat(0, 1ull); qstat(1, (unsigned long long)__popcll(__ballot(valid)));
+#endif
             // a slot for every ray of the group
             const u64 vb = __ballot(valid);
             const uint32_t nv = (uint32_t)__popcll(vb);
@@ -275,10 +279,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, c
                         pd = mk(wf[F_DX * R + psid], wf[F_DY * R + psid], wf[F_DZ * R + psid]);
                         first = cl[pc].first; count = cl[pc].count;
                     }
+#ifdef PT_CULL_STATS
+                    qstat(2, 1ull); qstat(3, (unsigned long long)__popcll(__ballot(pvalid)));
+                    { unsigned long long mt = (unsigned long long)count; for (int sft = 32; sft > 0; sft >>= 1) mt += __shfl_down(mt, sft); qstat(13, mt); }
+                    { int mx = count; for (int sft = 32; sft > 0; sft >>= 1) { const int t = __shfl_down(mx, sft); mx = t > mx ? t : mx; } qstat(15, (unsigned long long)mx); }
+#endif
                     const CullRay pr = make_cull_ray(po, pd);
                     // members' own bounds: per-lane gather from the geometry table; candidates -> the ray's list
                     auto append = [&](uint32_t p, float tn) {
                         const uint32_t pos = atomicAdd(&wl[F_META * R + psid], 1u);
+#ifdef PT_CULL_STATS
+                        atomicAdd(&g_cull_stats[10], 1ull);
+#endif
                         if (pos < kListCap) {
                             unsigned short *l16 = reinterpret_cast<unsigned short *>(&wl[(F_L0 + (pos >> 1)) * R + psid]) + (pos & 1u);
                             *l16 = (unsigned short)((quant_tn(tn, qscale) << 8) | p);
@@ -313,16 +325,57 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, c
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             // ---------------------------------------------------------------- SELECT: nearest candidate first
             bool queued = false, tobox = false;
+            const uint32_t ncand = valid ? wl[F_META * R + sid] : 0u;
+            // Rays whose list overflowed (rare: 2 in 10 000 on configs[3]) take the reference loop itself; its winner is then
+            // confirmed by one exact test in a TEST group.  A few of them: one ray at a time on the WHOLE wave, every lane
+            // testing G / 64 primitives (cubes first, in the order of the member table) + a min-reduction with the
+            // reference's tie rule -- a lane alone would keep the wave waiting for G exact tests.  Many: the per-lane loop.
+            int ovhit = -1;
+            {
+                const bool ov = ncand > kListCap;
+                const u64 ovb = __ballot(ov);
+#ifdef PT_CULL_STATS
+                qstat(11, (unsigned long long)__popcll(ovb));
+#endif
+                if (ovb) {
+                    if (__popcll(ovb) >= 12) {
+                        if (ov) { float tb; f3 P, N; ovhit = nearest_hit(lg, a.G, o, d, tb, P, N); }
+                    } else {
+                        u64 m = ovb;
+                        while (m) {
+                            const int src = (int)__builtin_ctzll(m);
+                            m &= m - 1ull;
+                            const f3 oo = mk(__shfl(o.x, src), __shfl(o.y, src), __shfl(o.z, src));
+                            const f3 dd = mk(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
+                            float bd = kInf;
+                            int bh = -1;
+                            for (int k = (int)lane; k < nmem; k += 64) {
+                                const int p = (int)members[k];               // every analytic primitive once: cubes, then spheres
+                                const GeomRec *g = lg + p;
+                                const bool pb = g->type == 1;
+                                float depth = -1.0f;
+                                f3 P, N;
+                                if (__any(pb)) { if (pb) depth = box_test(g->inv, g->xf, g->inside_hits, oo, dd, P, N); }
+                                if (__any(!pb)) { if (!pb) depth = sphere_test(g->inv, g->xf, oo, dd, P, N); }
+                                if (depth > -PT_EPSILON && (depth < bd || (depth == bd && p < bh))) { bd = depth; bh = p; }
+                            }
+#pragma unroll
+                            for (int sft = 32; sft > 0; sft >>= 1) {             // nearest wins, ties to the lower index
+                                const float od = __shfl_xor(bd, sft);
+                                const int oh = __shfl_xor(bh, sft);
+                                if (oh >= 0 && (bh < 0 || od < bd || (od == bd && oh < bh))) { bd = od; bh = oh; }
+                            }
+                            if ((int)lane == src) ovhit = bh;
+                        }
+                    }
+                }
+            }
             if (valid) {
-                const uint32_t cnt = wl[F_META * R + sid];
+                const uint32_t cnt = ncand;
                 uint32_t first_id = 0u;
                 if (cnt > kListCap) {
-                    // the list overflowed: the reference loop itself for this ray; its winner is confirmed by one exact test in a TEST group
-                    float tb;
-                    f3 P, N;
-                    const int h = nearest_hit(lg, a.G, o, d, tb, P, N);
-                    if (h >= 0) {
-                        first_id = (uint32_t)h; queued = true;
+                    if (ovhit >= 0) {
+                        first_id = (uint32_t)ovhit; queued = true;
                         wl[F_L0 * R + sid] = 0xFFFFFFFFu; wl[F_L1 * R + sid] = 0xFFFFFFFFu; wl[F_L2 * R + sid] = 0xFFFFFFFFu; wl[F_L3 * R + sid] = 0xFFFFFFFFu;
                     }
                 } else if (cnt != 0u) {
@@ -362,6 +415,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, c
         const bool valid = lane < cnt;
         const uint32_t qpos = isb ? (have - cnt + lane) : ((uint32_t)R - 1u - (have - cnt + lane));
         if (isb) nbox -= cnt; else nsph -= cnt;
+#ifdef PT_CULL_STATS
+        qstat(isb ? 4 : 6, 1ull); qstat(isb ? 5 : 7, (unsigned long long)cnt);
+#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                // payload stores of earlier groups have landed ...
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");                // ... before they are read back through the same L1
@@ -429,6 +485,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, c
             }
             nbx = lg[nid].type == 1;
         }
+#ifdef PT_CULL_STATS
+        qstat(8, (unsigned long long)__popcll(__ballot(done && has_hit))); qstat(9, (unsigned long long)__popcll(__ballot(done)));
+        qstat(12, (unsigned long long)__popcll(__ballot(more))); qstat(14, (unsigned long long)__popcll(__ballot(more && won)));
+#endif
         // ---------------------------------------------------------------- shade the finished rays that hit something
         bool alive = false;
         if (done && has_hit) {

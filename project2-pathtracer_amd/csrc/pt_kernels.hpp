@@ -274,7 +274,7 @@ __device__ __forceinline__ int nearest_hit_culled(const GeomRec *lg, const GeomR
 #define PT_CLUSTER 4                                  // preferred members per cluster; the host grows it until <= 64 clusters
 #endif
 #ifndef PT_CLUSTER_PATHW
-#define PT_CLUSTER_PATHW 8                            // k_path_w tests the members of a (ray, cluster) pair on dense waves: larger clusters pay
+#define PT_CLUSTER_PATHW 5                            // k_path_w: measured best on configs[3] (5: 1.08, 6: 1.12, 8: 1.16, 12: 1.24 ms/step, profiles/r03a_*)
 #endif
 constexpr int kClusterMax = 16;
 struct __attribute__((aligned(16))) ClusterRec {      // lives behind the geometry table in LDS, cube clusters first

@@ -113,7 +113,7 @@ def test_bench_line_states_what_bounds_the_kernel(pt):
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     roof = res["roofline"]
     assert roof["bound"] in ("valu-issue", "hbm") and roof["stated_roofline"].startswith("hbm")
-    assert roof["frac"] == pytest.approx(roof["algorithmic_bytes_per_step"] / (res["ms_per_step"] * 1e-3) / 8e12, abs=1e-4)
+    assert roof["frac"] == pytest.approx(roof["algorithmic_bytes_per_step"] / (res["ms_per_step"] * 1e-3) / 8e12, rel=2e-3)      # ms_per_step carries 4 decimals
     assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], abs=1e-4)
     assert roof["algorithmic_bytes_per_launch"] == pytest.approx(roof["algorithmic_bytes_per_step"] * res["steps"] / roof["launches"], rel=1e-6)
     src = roof["traffic_source"]

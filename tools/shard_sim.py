@@ -1,7 +1,7 @@
 """Per-rank cost of the row-sharded render as a function of the shard count, measured on ONE GPU:
 the contexts render only the rows one rank of an N-GPU job would own.  N x the per-step time against the
 1-GPU step time OF THE SAME RUN is the compute-side strong-scaling efficiency (exchange excluded).
-usage: python tools/shard_sim.py [streams=2] [key=value ...]   (contexts per rank, as bench.py --streams; pt_config fields,
+usage: python tools/shard_sim.py [streams=2] [scene=scenes/x.txt] [key=value ...]   (contexts per rank, as bench.py --streams; pt_config fields,
        worlds=8 restricts the shard counts)"""
 import importlib
 import os
@@ -12,9 +12,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("project2-pathtracer_amd")
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-KW = {k: int(v) for k, v in (a.split("=") for a in sys.argv[2:])}
+RAW = dict(a.split("=") for a in sys.argv[2:])
+SCENE = RAW.pop("scene", "scenes/cornell_mirror.txt")          # scene=scenes/random256.txt: configs[3]
+KW = {k: int(v) for k, v in RAW.items()}
 WORLDS = (1, KW.pop("worlds")) if "worlds" in KW else (1, 2, 4, 8)
-sf = pkg.SceneFile(os.path.join(ROOT, "scenes", "cornell_mirror.txt"))
+sf = pkg.SceneFile(os.path.join(ROOT, SCENE))
 g, m, cam = sf.flatten(0)
 base = {}
 for world in WORLDS:

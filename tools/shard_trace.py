@@ -11,8 +11,9 @@ sys.path.insert(0, ROOT)
 pkg = importlib.import_module("project2-pathtracer_amd")
 KW = dict(a.split("=") for a in sys.argv[1:])
 world, S, steps, passes = (int(KW.pop(k, d)) for k, d in (("world", 8), ("streams", 2), ("steps", 20), ("passes", 6)))
+SCENE = KW.pop("scene", "scenes/cornell_mirror.txt")
 KW = {k: int(v) for k, v in KW.items()}
-sf = pkg.SceneFile(os.path.join(ROOT, "scenes", "cornell_mirror.txt"))
+sf = pkg.SceneFile(os.path.join(ROOT, SCENE))
 g, m, cam = sf.flatten(0)
 tr = pkg.PathTracer(pkg.default_config(**dict(dict(max_depth=8, ordering=1, row_offset=0, row_stride=world, streams=S), **KW)))
 tr.upload(g, m, cam)

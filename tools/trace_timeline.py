@@ -3,7 +3,7 @@ gap to the previous launch on the same queue.  usage: python tools/trace_timelin
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f))]
-rows = [r for r in rows if "k_bounce" in r["Kernel_Name"] or "k_fold" in r["Kernel_Name"]]
+rows = [r for r in rows if "k_bounce" in r["Kernel_Name"] or "k_fold" in r["Kernel_Name"] or "k_path" in r["Kernel_Name"] or "fillBuffer" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # passes are separated by idle gaps > 1 ms
 groups, cur, last_end = [], [], None
