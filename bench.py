@@ -219,6 +219,7 @@ def main():
                                                              "2 = whole paths, one launch per group: k_path_q (<= 32 primitives) / k_path_w (33..256 analytic primitives)")
     ap.add_argument("--wide-variant", type=int, default=0, help="k_path_w block shape (A/B switch, results identical)")
     ap.add_argument("--cluster-size", type=int, default=0, help="members per spatial cluster for scenes of 33..256 primitives (0 = default)")
+    ap.add_argument("--grid-density", type=int, default=0, help="k_path_w: cells of its uniform grid per small primitive (0 = default 4)")
     ap.add_argument("--static-eighths", type=int, default=4, help="whole-path kernels: eighths of the camera-ray jobs owned statically by the waves")
     ap.add_argument("--batch", type=int, default=0, help="iterations per launch group (0 = auto, 1 = off)")
     ap.add_argument("--resolution", default="", help="WxH override of the scene RES line (experiments only)")
@@ -301,7 +302,7 @@ def main():
     tracer = pkg.PathTracer(pkg.default_config(device=device, max_depth=depth, row_offset=rank, row_stride=world, streams=S,
                                                chunk_rays=args.chunk_rays, blocks_per_cu=args.blocks_per_cu, culling=args.culling, batch=args.batch,
                                                ordering=args.ordering, direct_light=args.direct_light, wide_variant=args.wide_variant,
-                                               cluster_size=args.cluster_size, path_static_eighths=args.static_eighths, **options))
+                                               cluster_size=args.cluster_size, grid_density=args.grid_density, path_static_eighths=args.static_eighths, **options))
     meshes = sf.meshes()
     if meshes:
         tracer.set_meshes(meshes)

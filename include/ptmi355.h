@@ -34,8 +34,9 @@ extern "C" {
  * 6: ordering = 2 is back with a new meaning: whole paths on the typed work queues, one launch per group
  * 7: geometry_path, compaction = 1 (look-back scan) and merge_floor are gone (measured slower; the fields stay and
  *    must be 0); reserved[3] became cluster_size / path_static_eighths / wide_variant (they replace environment
- *    switches the library used to read); ordering = 2 also covers scenes of 33..256 analytic primitives (k_path_w) */
-#define PTMI355_ABI_VERSION 7
+ *    switches the library used to read); ordering = 2 also covers scenes of 33..256 analytic primitives (k_path_w)
+ * 8: + pt_config.grid_density (k_path_w walks a uniform grid over the small primitives instead of testing every cluster box) */
+#define PTMI355_ABI_VERSION 8
 
 typedef enum {
     PT_OK = 0,
@@ -120,8 +121,9 @@ typedef struct {
                                 2 = whole paths on the typed work queues: ONE launch per group; waves draw jobs of camera
                                     rays from a ticket counter and keep every ray from the camera to its end (queue records
                                     carry the ray and its bounce level, survivors wait on small per-wave stacks);
-                                    <= 32 primitives: k_path_q; 33..256 analytic primitives: k_path_w (dense (ray, cluster)
-                                    pairs, type-pure exact tests on full waves); results identical.  Other values behave like 0. */
+                                    <= 32 primitives: k_path_q; 33..256 analytic primitives: k_path_w (rays walk a uniform grid;
+                                    dense (ray, cell) and (ray, primitive) pairs, type-pure exact tests on full waves); results
+                                    identical.  Other values behave like 0. */
     int   bvh;               /* unused (round-1 experiments, removed); scenes with 33..256 analytic primitives use
                                 two-level cluster culling automatically, meshes carry their own BVH */
     int   direct_light;      /* 1 = next-event estimation: at every diffuse hit one shadow
@@ -138,8 +140,10 @@ typedef struct {
                                 culling (0 = default; the library grows it until the clusters fit their mask) */
     int   path_static_eighths; /* whole-path kernels: share of the camera-ray jobs every wave owns statically, in
                                 eighths (pt_config_default: 4 = half); the rest is drawn from ticket counters */
-    int   wide_variant;      /* k_path_w block shape: 0 = default, 1..3 = other waves-per-block / ray-slot splits of
+    int   wide_variant;      /* k_path_w block shape: 0 = default, 1..2 = other waves-per-block / ray-slot splits of
                                 the CU's LDS (A/B switch; results identical) */
+    int   grid_density;      /* k_path_w: cells of its uniform grid per small primitive (0 = default 4; 1..64).  The grid only
+                                decides which bounds a ray tests; results identical. */
 } pt_config;
 
 typedef struct pt_context pt_context;
@@ -244,6 +248,15 @@ int  pt_debug_sincos(pt_context *ctx, int n, const float *a, float *s, float *c)
 /* getRandomPointOnCube / getRandomPointOnSphere (src/intersections.h:220-286) on primitive `geom`
  * of the uploaded scene for n float seeds (the reference's light-sampling helpers; no call sites there) */
 int  pt_debug_light_points(pt_context *ctx, int geom, int n, const float *seeds, float *out3);
+
+/* The spatial index of the whole-path kernel for 33..256 primitives, probed WITHOUT a device: builds the uniform grid of
+ * the scene as pt_upload_scene does and walks nrays rays (6 floats each: origin, direction) on the host with the kernel's
+ * own walk functions.  out_sets: nrays x 8 words, bit p of a ray = primitive p gets its bound tested for that ray (every
+ * bit for a ray the kernel would not walk: it takes the reference loop).  out_info[16]: [0] cells [1] references [2] big
+ * primitives [3] primitives listed twice for a ray (must be 0) [4] rays not walked [5..7] cells per axis [8] mean and
+ * [9] longest walk in cells [10] non-empty cells and [11] listed primitives per ray x 100 [12] bytes of LDS. */
+int  pt_debug_grid_probe(const pt_geom *geoms, int ngeoms, int density, const float *rays, int nrays,
+                         uint32_t *out_sets, uint32_t *out_info);
 
 /* ---- host-side scene I/O (no GPU needed; src/scene.cpp grammar, src/image.cpp output) ---- */
 

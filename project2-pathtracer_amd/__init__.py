@@ -48,7 +48,7 @@ class Config(C.Structure):     # == pt_config
                 ("row_offset", C.c_int), ("row_stride", C.c_int), ("geometry_path", C.c_int),
                 ("chunk_rays", C.c_int), ("blocks_per_cu", C.c_int), ("profile", C.c_int),
                 ("compaction", C.c_int), ("culling", C.c_int), ("merge_floor", C.c_int), ("batch", C.c_int), ("ordering", C.c_int), ("bvh", C.c_int), ("direct_light", C.c_int), ("streams", C.c_int),
-                ("cluster_size", C.c_int), ("path_static_eighths", C.c_int), ("wide_variant", C.c_int)]
+                ("cluster_size", C.c_int), ("path_static_eighths", C.c_int), ("wide_variant", C.c_int), ("grid_density", C.c_int)]
 
 
 class Mesh(C.Structure):       # == pt_mesh
@@ -109,6 +109,7 @@ def lib():
     L.pt_debug_hemisphere.argtypes = [vp, C.c_int, fp, fp, fp]
     L.pt_debug_sincos.argtypes = [vp, C.c_int, fp, fp, fp]
     L.pt_debug_light_points.argtypes = [vp, C.c_int, C.c_int, fp, fp]
+    L.pt_debug_grid_probe.argtypes = [C.POINTER(Geom), C.c_int, C.c_int, fp, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.pt_scene_load.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.pt_scene_free.argtypes = [vp]; L.pt_scene_free.restype = None
     L.pt_scene_counts.argtypes = [vp, ip, ip, ip, ip]
@@ -126,7 +127,7 @@ EXPORTS = [
     "pt_abi_version", "pt_last_error", "pt_config_default", "pt_device_count", "pt_create", "pt_destroy",
     "pt_upload_scene", "pt_set_meshes", "pt_scene_mesh_count", "pt_scene_mesh", "pt_set_image", "pt_bind_device_image", "pt_get_image", "pt_get_rows", "pt_gather_rows_peer", "pt_render", "pt_sync",
     "pt_display", "pt_set_profiling", "pt_get_stats", "pt_reset_stats", "pt_get_resolution", "pt_debug_primary_hits",
-    "pt_debug_trace_pool", "pt_debug_set_turn_limit", "pt_debug_rng_from_thread", "pt_debug_hemisphere", "pt_debug_sincos", "pt_debug_light_points",
+    "pt_debug_trace_pool", "pt_debug_set_turn_limit", "pt_debug_rng_from_thread", "pt_debug_hemisphere", "pt_debug_sincos", "pt_debug_light_points", "pt_debug_grid_probe",
     "pt_scene_load", "pt_scene_free", "pt_scene_counts", "pt_scene_image_name", "pt_scene_flatten",
     "pt_scene_object_matrices", "pt_build_transform", "pt_image_to_u8", "pt_image_save",
 ]
@@ -331,6 +332,22 @@ class PathTracer:
             self.close()
         except Exception:
             pass
+
+
+def grid_probe(geoms, rays, density=0):
+    """k_path_w's spatial index probed on the host (no device): (sets, info) for rays[n, 6] = origin + direction.
+    sets[n, 256] (bool): primitive p gets its bound tested for ray n; info: dict of the grid's figures."""
+    import numpy as np
+    rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+    n = rays.shape[0]
+    words = np.zeros((n, 8), dtype=np.uint32)
+    info = np.zeros(16, dtype=np.uint32)
+    _check(lib().pt_debug_grid_probe(geoms, len(geoms), int(density), _fp(rays), n,
+                                     words.ctypes.data_as(C.POINTER(C.c_uint32)), info.ctypes.data_as(C.POINTER(C.c_uint32))))
+    sets = np.unpackbits(words.view(np.uint8), axis=1, bitorder="little").astype(bool)
+    names = ["cells", "refs", "big", "duplicates", "unwalked", "nx", "ny", "nz", "mean_walk", "longest_walk",
+             "cells_per_ray_x100", "listed_per_ray_x100", "lds_bytes"]
+    return sets, {k: int(v) for k, v in zip(names, info)}
 
 
 def build_transform(t, r, s):

@@ -50,6 +50,8 @@ struct pt_context {
     int wide_variant = 0;            //   k_path_w: block shape / slots per wave (cfg.wide_variant)
     uint32_t wide_stack = 0, wide_slots = 0;
     float wide_qscale = 1.0f, wide_slack = 0.0f;
+    GridArgs grid;                   //   k_path_w: the uniform grid over the small primitives (build_grid)
+    unsigned char *d_grid = nullptr; //   its blob: cells | refs | big list
     uint32_t turn_limit = 0;         // whole-path kernels: explicit guard against a wave that never finishes (0 = by launch size; pt_debug_set_turn_limit)
     int occ_bounce = 2;              // resident blocks per CU of the per-bounce kernel in use
     uint32_t lds_path = 0;
@@ -155,6 +157,8 @@ void free_scene_buffers(pt_context *c) {
     c->d_cull = nullptr;
     if (c->d_arena) (void)hipFree(c->d_arena);
     c->d_arena = nullptr;
+    if (c->d_grid) (void)hipFree(c->d_grid);
+    c->d_grid = nullptr;
     if (c->d_tickets) (void)hipFree(c->d_tickets);
     c->d_tickets = nullptr;
     for (void *b : c->d_mesh_blobs) (void)hipFree(b);
@@ -219,6 +223,134 @@ void world_bounds(const pt_geom &src, GeomRec *dst) {
     }
     // the sphere test reports the point 1e-4 (object space, along the ray) in front of the surface
     dst->slack = src.type == 0 ? (float)(1.5e-4 * maxrow + 1e-5) : 1e-5f;
+}
+
+// ---- k_path_w: uniform grid over the small analytic primitives (GridArgs, pt_kernels.hpp) ---------------------
+// Cell size: about `density` cells per small primitive over the box of their bounds (cubic cells, at most kGridMaxCells).
+// A primitive whose bound (grown by the margin below) meets more than kGridBigCells cells is BIG: it stays out of the
+// grid and every ray tests its bound.  Too many big ones (each costs every ray a bound test, and more than 8 hit
+// candidates of a ray overflow its list): the grid is rebuilt coarser, until few are left or the grid is one cell.
+// Margin: cells list a primitive over its conservative bound grown by 2e-3 cell sizes + 1e-5 of the largest
+// coordinate.  The walk's float error (boundaries rebuilt from integer indices, distances as (b - o) * 1/d) stays
+// below 1e-5 of the scene's diagonal for rays starting within `reach` = 8 diagonals of the centre, a tenth of the margin;
+// farther or non-finite rays are not walked at all (the kernel gives them the reference loop).
+struct GridBuild { GridArgs ga; std::vector<unsigned char> blob; };
+
+void build_grid(const std::vector<GeomRec> &g, int G, int density, GridBuild *out) {
+    struct Box { double lo[3], hi[3]; int id; bool sphere; };
+    std::vector<Box> prims;
+    double maxabs = 0.0;
+    for (int i = 0; i < G; ++i) {
+        if (g[i].type != 0 && g[i].type != 1) continue;                  // MESH without data: in no list, like the reference's empty branch
+        Box b;
+        b.id = i; b.sphere = g[i].type == 0;
+        for (int k = 0; k < 3; ++k) {
+            b.lo[k] = b.sphere ? (double)g[i].bmin[k] - (double)g[i].bmax[3] : (double)g[i].bmin[k];
+            b.hi[k] = b.sphere ? (double)g[i].bmin[k] + (double)g[i].bmax[3] : (double)g[i].bmax[k];
+            maxabs = std::fmax(maxabs, std::fmax(std::fabs(b.lo[k]), std::fabs(b.hi[k])));
+        }
+        prims.push_back(b);
+    }
+    GridArgs ga;
+    memset(&ga, 0, sizeof ga);
+    std::vector<char> big(prims.size(), 0);
+    std::vector<std::vector<uint16_t>> lists;
+    double dens = density > 0 ? (double)density : 4.0;
+    int n[3] = {1, 1, 1};
+    double gmin[3] = {0, 0, 0}, h[3] = {1, 1, 1};
+    for (int attempt = 0; attempt < 12; ++attempt) {
+        std::fill(big.begin(), big.end(), 0);
+        size_t nbig = 0;
+        for (int pass = 0; pass < 3; ++pass) {                             // bounds of the small ones -> cells -> who is big -> again
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            size_t m = 0;
+            for (size_t q = 0; q < prims.size(); ++q) {
+                if (big[q]) continue;
+                m++;
+                for (int k = 0; k < 3; ++k) { lo[k] = std::fmin(lo[k], prims[q].lo[k]); hi[k] = std::fmax(hi[k], prims[q].hi[k]); }
+            }
+            if (m == 0) { for (int k = 0; k < 3; ++k) { lo[k] = -1.0; hi[k] = 1.0; } }
+            double ext[3], vol = 1.0, emax = 0.0;
+            for (int k = 0; k < 3; ++k) { ext[k] = hi[k] - lo[k]; emax = std::fmax(emax, ext[k]); }
+            if (!(emax > 0.0)) emax = 1.0;
+            for (int k = 0; k < 3; ++k) { if (ext[k] < 1e-3 * emax) ext[k] = 1e-3 * emax; vol *= ext[k]; }
+            double cell = std::cbrt(vol / (dens * (double)(m > 0 ? m : 1)));
+            for (;;) {
+                uint64_t total = 1;
+                for (int k = 0; k < 3; ++k) { n[k] = (int)std::ceil(ext[k] / cell); if (n[k] < 1) n[k] = 1; total *= (uint64_t)n[k]; }
+                if (total <= kGridMaxCells) break;
+                cell *= 1.1;
+            }
+            for (int k = 0; k < 3; ++k) {
+                const double pad = 4e-3 * cell + 4e-5 * maxabs;               // the grid's box reaches beyond every listed bound and its margin
+                h[k] = (ext[k] + 2.0 * pad) / (double)n[k];
+                gmin[k] = lo[k] - pad;
+                // the kernel's numbers are these floats
+                h[k] = (double)(float)h[k]; gmin[k] = (double)(float)gmin[k];
+            }
+            nbig = 0;
+            for (size_t q = 0; q < prims.size(); ++q) {
+                uint64_t cellsq = 1;
+                for (int k = 0; k < 3; ++k) {
+                    const double mg = 2e-3 * h[k] + 1e-5 * maxabs;
+                    int c0 = (int)std::floor((prims[q].lo[k] - mg - gmin[k]) / h[k]), c1 = (int)std::floor((prims[q].hi[k] + mg - gmin[k]) / h[k]);
+                    c0 = std::max(c0, 0); c1 = std::min(c1, n[k] - 1);
+                    cellsq *= (uint64_t)(c1 >= c0 ? c1 - c0 + 1 : 1);
+                }
+                // a primitive once found big stays big for this attempt (the grid only gets finer as they leave)
+                if (cellsq > (uint64_t)kGridBigCells || big[q]) { big[q] = 1; nbig++; }
+            }
+        }
+        if (nbig <= 8 || dens < 0.02) break;
+        dens *= 0.5;                                                       // coarser cells: fewer primitives are big
+    }
+    // the lists
+    const uint32_t ncells = (uint32_t)(n[0] * n[1] * n[2]);
+    lists.assign(ncells, {});
+    std::vector<unsigned char> bigs;
+    for (size_t q = 0; q < prims.size(); ++q) {
+        if (big[q]) { bigs.push_back((unsigned char)prims[q].id); continue; }
+        int c0[3], c1[3];
+        for (int k = 0; k < 3; ++k) {
+            const double mg = 2e-3 * h[k] + 1e-5 * maxabs;
+            c0[k] = (int)std::floor((prims[q].lo[k] - mg - gmin[k]) / h[k]); c1[k] = (int)std::floor((prims[q].hi[k] + mg - gmin[k]) / h[k]);
+            c0[k] = std::min(std::max(c0[k], 0), n[k] - 1); c1[k] = std::min(std::max(c1[k], 0), n[k] - 1);
+        }
+        for (int z = c0[2]; z <= c1[2]; ++z)
+            for (int y = c0[1]; y <= c1[1]; ++y)
+                for (int x = c0[0]; x <= c1[0]; ++x) {
+                    uint32_t flags = prims[q].sphere ? 0x80u : 0u;
+                    if (x == c0[0]) flags |= 1u; if (y == c0[1]) flags |= 2u; if (z == c0[2]) flags |= 4u;
+                    if (x == c1[0]) flags |= 8u; if (y == c1[1]) flags |= 16u; if (z == c1[2]) flags |= 32u;
+                    lists[(size_t)x + (size_t)n[0] * ((size_t)y + (size_t)n[1] * (size_t)z)].push_back((uint16_t)((uint32_t)prims[q].id | (flags << 8)));
+                }
+    }
+    std::vector<uint32_t> cellrec(ncells, 0u);
+    std::vector<uint16_t> refs;
+    for (uint32_t cI = 0; cI < ncells; ++cI) {
+        cellrec[cI] = (uint32_t)refs.size() | ((uint32_t)lists[cI].size() << 16);
+        refs.insert(refs.end(), lists[cI].begin(), lists[cI].end());
+        if (!lists[cI].empty()) refs.back() |= 0x4000u;                  // the cell's last reference
+    }
+    // (<= 256 primitives x <= kGridBigCells cells each = 6 912 references: the 16-bit fields hold them)
+    const size_t nrefs = refs.size(), nrefs_even = (nrefs + 1) & ~(size_t)1;
+    size_t bytes = (size_t)ncells * 4 + nrefs_even * 2 + bigs.size();
+    bytes = (bytes + 15) & ~(size_t)15;
+    out->blob.assign(bytes, 0);
+    memcpy(out->blob.data(), cellrec.data(), (size_t)ncells * 4);
+    if (nrefs) memcpy(out->blob.data() + (size_t)ncells * 4, refs.data(), nrefs * 2);
+    if (!bigs.empty()) memcpy(out->blob.data() + (size_t)ncells * 4 + nrefs_even * 2, bigs.data(), bigs.size());
+    double diag2 = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        ga.gmin[k] = (float)gmin[k]; ga.h[k] = (float)h[k]; ga.inv_h[k] = (float)(1.0 / h[k]); ga.n[k] = n[k];
+        ga.centre[k] = (float)(gmin[k] + 0.5 * h[k] * n[k]);
+        diag2 += (h[k] * n[k]) * (h[k] * n[k]);
+    }
+    ga.reach = (float)(8.0 * std::sqrt(diag2));
+    ga.ncells = ncells; ga.nrefs = (uint32_t)nrefs; ga.nbig = (uint32_t)bigs.size();
+    ga.blob_bytes = (uint32_t)bytes;
+    ga.blob = nullptr;
+    out->ga = ga;
 }
 
 // ---- MESH: threaded BVH over the triangles of one mesh (object space), built at upload ----------------------
@@ -418,7 +550,7 @@ int enqueue_iterations(pt_context *c, uint32_t iteration, uint32_t batch, int st
         HIPCHK(hipMemsetAsync(pa.ticket, 0, (size_t)kTicketCtrs * kTicketStride * sizeof(uint32_t), c->stream));
         {
             Scoped s(c, 1);
-            if (c->pathw) wide_launch(c->wide_variant, c->grid_path, c->lds_path, c->stream, a, pa, c->d_geoms, c->d_mats, c->d_frames);
+            if (c->pathw) wide_launch(c->wide_variant, c->grid_path, c->lds_path, c->stream, a, pa, c->grid, c->d_geoms, c->d_mats, c->d_frames);
             else path_launch(c->queue_mesh, c->grid_path, c->lds_path, c->stream, a, pa, c->d_geoms, c->d_mats, qt);
             HIPCHK(hipGetLastError());
         }
@@ -495,6 +627,7 @@ int pt_create(const pt_config *cfg, pt_context **out) {
     }
     if (cfg->path_static_eighths < 0 || cfg->path_static_eighths > 8) { pth::set_error("pt_create: path_static_eighths %d not in 0..8", cfg->path_static_eighths); return PT_ERR_ARGUMENT; }
     if (cfg->cluster_size < 0 || cfg->cluster_size > 16) { pth::set_error("pt_create: cluster_size %d not in 0..16", cfg->cluster_size); return PT_ERR_ARGUMENT; }
+    if (cfg->grid_density < 0 || cfg->grid_density > 64) { pth::set_error("pt_create: grid_density %d not in 0..64", cfg->grid_density); return PT_ERR_ARGUMENT; }
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
         pth::set_error("pt_create: no HIP device visible (this library has no CPU fallback)");
@@ -698,21 +831,21 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     // 33..256 analytic primitives with the table in LDS: two-level cluster culling (the stable kernel's WIDE variant;
     // with ordering = 2 the whole-path kernel k_path_w renders and this variant serves the parity hooks)
     c->wide = c->cull && c->geom_lds && !c->nee && !c->queue && !have_mesh && c->cfg.mode == 0 && G > 32 && G <= 256;
-    c->pathw = c->wide && c->cfg.ordering == 2;
+    c->pathw = c->wide && c->cfg.ordering == 2;                 // (kept when the clusters below do not fit their mask: k_path_w has its own index)
     // two-level culling of the many-primitive variant: clusters of <= kClusterSize primitives of one type
     std::vector<unsigned char> cluster_blob;
     c->nbc = c->nsc = 0; c->cluster_bytes = 0;
     if (c->wide) {
         std::vector<ClusterRec> recs;
         std::vector<unsigned char> ids;
-        int csize = c->cfg.cluster_size > 0 ? c->cfg.cluster_size : (c->pathw ? PT_CLUSTER_PATHW : PT_CLUSTER);
+        int csize = c->cfg.cluster_size > 0 ? c->cfg.cluster_size : PT_CLUSTER;
         if (csize < 1) csize = 1;
         if (csize > kClusterMax) csize = kClusterMax;
-        for (; csize <= kClusterMax; ++csize) {                // the per-lane cluster masks: 64 bits in all, 32 per type for k_path_w
+        for (; csize <= kClusterMax; ++csize) {                // the per-lane cluster mask: 64 bits in all
             int nb = 0, ns = 0;
             for (int i = 0; i < G; ++i) { if (g[i].type == 1) nb++; else if (g[i].type == 0) ns++; }
             const int cb = (nb + csize - 1) / csize, cs = (ns + csize - 1) / csize;
-            if (cb + cs <= 64 && (!c->pathw || (cb <= 32 && cs <= 32))) break;
+            if (cb + cs <= 64) break;
         }
         if (csize > kClusterMax) csize = kClusterMax;
         for (int pass = 0; pass < 2; ++pass) {
@@ -758,8 +891,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
                 if (pass == 0) c->nbc++; else c->nsc++;
             }
         }
-        if (c->pathw && (c->nbc > 32 || c->nsc > 32)) c->pathw = false;
-        if (c->nbc + c->nsc > 64) { c->wide = false; c->pathw = false; }            // the per-lane cluster mask has 64 bits
+        if (c->nbc + c->nsc > 64) c->wide = false;                                   // the per-lane cluster mask has 64 bits (the parity hooks then run the one-level culling)
         else {
             const size_t idbytes = (ids.size() + 15) & ~(size_t)15;
             cluster_blob.assign(recs.size() * sizeof(ClusterRec) + idbytes, 0);
@@ -888,9 +1020,20 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     if (c->pathw) {
         // ordering = 2 with 33..256 analytic primitives: k_path_w -- one big block per CU shares the geometry table; per-wave
         // ray slots and work stacks in LDS, the survivors' stacks and the slots' payload in one arena per wave
+        GridBuild gb;
+        build_grid(g, G, c->cfg.grid_density, &gb);
+        c->grid = gb.ga;
+        HIPCHK(hipMalloc(&c->d_grid, gb.blob.size()));
+        HIPCHK(hipMemcpy(c->d_grid, gb.blob.data(), gb.blob.size(), hipMemcpyHostToDevice));
+        c->grid.blob = c->d_grid;
         WideLayout wl;
         c->wide_variant = c->cfg.wide_variant;
-        HIPCHK(wide_setup(c->wide_variant, G, M, c->cluster_bytes, &wl));
+        {
+            // the block shape asked for, or the next one that leaves room for the grid beside the tables
+            hipError_t e = wide_setup(c->wide_variant, G, M, c->grid.blob_bytes, &wl);
+            for (int v = 0; e == hipErrorInvalidValue && v < 3; ++v) { c->wide_variant = v; e = wide_setup(v, G, M, c->grid.blob_bytes, &wl); }
+            HIPCHK(e);
+        }
         c->lds_path = wl.lds_bytes;
         c->path_waves = wl.waves_per_block;
         c->grid_path = c->n_cu * (c->cfg.blocks_per_cu > 0 ? 1 : 1);
@@ -1080,7 +1223,64 @@ int pt_debug_cull_stats(unsigned long long *out16) {       // analysis builds (-
     cull_stats_seg(out16); cull_stats_queue(out16); cull_stats_path(out16); cull_stats_wide(out16);
     return 0;
 }
+extern "C" int pt_debug_phase_cycles(unsigned long long *out16) { phase_cycles_wide(out16); return 0; }   // k_path_w's phase clock
+extern "C" int pt_debug_wide_stats(unsigned long long *out32) { stats_wide(out32); return 0; }             // k_path_w's stage statistics
 #endif
+
+// CPU-side probe of k_path_w's spatial index (no device needed): builds the grid of the scene exactly as pt_upload_scene
+// does and walks `nrays` rays (o.xyz, d.xyz each) ON THE HOST with the kernel's own walk functions and flag logic.
+int pt_debug_grid_probe(const pt_geom *geoms, int G, int density, const float *rays, int nrays, uint32_t *out_sets, uint32_t *out_info) {
+    if (!geoms || G < 1 || G > 256 || !rays || nrays < 0 || !out_sets || !out_info) { pth::set_error("pt_debug_grid_probe: bad argument"); return PT_ERR_ARGUMENT; }
+    std::vector<GeomRec> g(G);
+    for (int i = 0; i < G; ++i) { memset(&g[i], 0, sizeof(GeomRec)); g[i].type = geoms[i].type; world_bounds(geoms[i], &g[i]); }
+    GridBuild gb;
+    build_grid(g, G, density, &gb);
+    const GridArgs &ga = gb.ga;
+    const uint32_t *cells = reinterpret_cast<const uint32_t *>(gb.blob.data());
+    const uint16_t *refs = reinterpret_cast<const uint16_t *>(cells + ga.ncells);
+    const unsigned char *bigs = reinterpret_cast<const unsigned char *>(refs + ((ga.nrefs + 1u) & ~1u));
+    uint32_t dups = 0, unwalked = 0, maxtrips = 0;
+    uint64_t trips_total = 0, entries = 0, news = 0;
+    for (int r = 0; r < nrays; ++r) {
+        uint32_t *set = out_sets + (size_t)r * 8;
+        for (int k = 0; k < 8; ++k) set[k] = 0u;
+        for (uint32_t k = 0; k < ga.nbig; ++k) set[bigs[k] >> 5] |= 1u << (bigs[k] & 31);
+        const f3 o = mk(rays[6 * r], rays[6 * r + 1], rays[6 * r + 2]), d = mk(rays[6 * r + 3], rays[6 * r + 4], rays[6 * r + 5]);
+        if (!grid_walk_sane(ga, o, d)) { unwalked++; for (int k = 0; k < 8; ++k) set[k] = 0xFFFFFFFFu; continue; }     // the kernel tests every primitive
+        auto grcp = [](float x) { const float ax = std::fabs(x); const float gg = ax < 1e-30f ? std::copysign(1e-30f, x) : x; return 1.0f / gg; };
+        const f3 inv = mk(grcp(d.x), grcp(d.y), grcp(d.z));
+        GridWalk w = grid_walk_begin(ga, o, d, inv, true);
+        const uint32_t cap = (uint32_t)(ga.n[0] + ga.n[1] + ga.n[2]) + 2u;
+        uint32_t trips = 0;
+        while (w.walking && trips < cap) {
+            trips++;
+            const uint32_t rec = cells[grid_walk_cell(w)];
+            if (rec >> 16) {
+                entries++;
+                for (uint32_t k = rec & 0xFFFFu;; ++k) {                  // the kernel's CELLS stage: one reference per entry, the next one re-queued
+                    const uint32_t ref = refs[k];
+                    if (grid_ref_is_new(ref, w.emask)) {
+                        const uint32_t p = ref & 0xFFu;
+                        if (set[p >> 5] & (1u << (p & 31))) dups++;
+                        set[p >> 5] |= 1u << (p & 31);
+                        news++;
+                    }
+                    if (ref & 0x4000u) break;
+                }
+            }
+            grid_walk_step(w);
+        }
+        if (w.walking) dups += 1000000u;                                   // the step bound must never cut a walk short
+        trips_total += trips;
+        if (trips > maxtrips) maxtrips = trips;
+    }
+    out_info[0] = ga.ncells; out_info[1] = ga.nrefs; out_info[2] = ga.nbig; out_info[3] = dups; out_info[4] = unwalked;
+    out_info[5] = (uint32_t)ga.n[0]; out_info[6] = (uint32_t)ga.n[1]; out_info[7] = (uint32_t)ga.n[2];
+    out_info[8] = (uint32_t)(nrays ? trips_total / (uint64_t)nrays : 0); out_info[9] = maxtrips;
+    out_info[10] = (uint32_t)(nrays ? (100 * entries) / (uint64_t)nrays : 0); out_info[11] = (uint32_t)(nrays ? (100 * news) / (uint64_t)nrays : 0);
+    out_info[12] = ga.blob_bytes;
+    return PT_OK;
+}
 
 int pt_set_profiling(pt_context *c, int enabled) {
     if (!c) { pth::set_error("pt_set_profiling: null context"); return PT_ERR_ARGUMENT; }

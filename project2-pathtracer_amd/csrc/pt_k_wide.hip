@@ -4,22 +4,30 @@
 // The nearest-hit loop it replaces is type- and count-agnostic (/root/reference/src/raytraceKernel.cu:134-153: every
 // primitive, first strictly nearer wins, ties to the lower index).  The lock-step kernel for these scenes
 // (k_bounce_seg<WIDE>, pt_k_seg.hip) finds the same hits with a two-level culling, but its per-lane loops leave the
-// wave mostly idle: the walk over a lane's clusters runs at 24 of 64 lanes, the exact cube tests at 22, the exact
-// sphere tests at 7 (profiles/r02i_cullstats_c4.log).  Here the unit of work is no longer "a ray":
+// wave mostly idle (cluster walk at 24 of 64 lanes, exact cube tests at 22, exact sphere tests at 7:
+// profiles/r02i_cullstats_c4.log), and its wave-uniform pass over every cluster box is paid by every ray wherever it
+// goes.  Here a ray only meets the primitives near its own path, and the unit of work is no longer "a ray":
 //
 //   FRESH   64 rays (the top of the wave's stack of survivors, or a job of camera rays) take a RAY SLOT each in the
 //           wave's LDS region (origin + direction, an 8-entry candidate list, best depth / hit so far) and park
-//           throughput, pixel word and level in the slot's payload record in global memory.  A wave-uniform pass tests
-//           the <= 32 + 32 cluster boxes (cube clusters / sphere clusters) and leaves two 32-bit masks per lane.
-//   PAIRS   the (ray, cluster) pairs of those 64 rays are EXPANDED: ballot-free prefix sums give every pair its index,
-//           the lanes write their pairs into a small LDS buffer (a cheap per-lane loop: ctz, store), and the wave then
-//           processes the buffer 64 pairs at a time -- lane = one pair: gather the ray from its slot, test the
-//           cluster's members' own bounds (cubes first, then spheres: one code path per group but the boundary one),
-//           append every candidate to the ray's list as a 16-bit key (quantised conservative entry distance, id).
-//           Full waves whatever a single ray's cluster count is.
+//           throughput, pixel word and level in the slot's payload record in global memory.  The few BIG primitives
+//           (walls: listed in too many cells to be worth a grid entry) have their bounds tested by every ray in a
+//           wave-uniform loop.
+//   WALK    every ray steps through the cells of a uniform grid over the small primitives (3D-DDA, one cell per
+//           trip; boundaries are rebuilt from the integer cell index, never accumulated).  A step into a non-empty
+//           cell leaves a (ray, cell, axes stepped) entry in a small LDS buffer.
+//   CELLS   64 such entries at a time, lane = one entry = one REFERENCE of the cell's list: a primitive that is NEW to
+//           the ray there -- decided by integer flags stored with the reference (GridArgs, pt_kernels.hpp), no
+//           arithmetic on distances -- goes on as a (ray, primitive) entry, cubes and spheres to the two ends of a
+//           second buffer; unless the reference is its cell's last, the entry returns to the buffer for the next
+//           one (so a crowded cell never holds a wave in a loop).
+//   BOUNDS  64 (ray, primitive) entries of one type, lane = one entry: gather the ray from its slot, test the
+//           primitive's own conservative bound, append a candidate to the ray's list as a 16-bit key (quantised
+//           conservative entry distance, id).
 //   SELECT  every ray picks its nearest candidate (smallest key) and waits on one of two wave-private stacks of slot
-//           ids by that candidate's TYPE.  A ray whose list overflowed (> 8 candidates: rare) takes the reference
-//           loop itself on the spot and waits for one confirming test of the winner.
+//           ids by that candidate's TYPE.  A ray whose list overflowed (> 8 candidates: rare), or that cannot be
+//           walked (non-finite, or so far from the grid that its float error exceeds the margin the cells were filled
+//           with), takes the reference loop itself on the spot and waits for one confirming test of the winner.
 //   TEST    pops 64 slots of one type: the exact reference test of the current candidate on all lanes; the winner so
 //           far is kept as (depth, id, face) in the slot.  Then the next candidate that could still win or tie -- key
 //           distance not beyond the best hit -- is selected by a branch-free scan of the 8 keys (no re-evaluation of
@@ -28,13 +36,29 @@
 //           (RNG stream of its own level, scatter, emitters -> memory-side float atomics), its slot freed, a survivor
 //           pushed on the wave's stack in global memory for the next bounce.
 //
-// Nothing leaves the wave: no barrier, no inter-wave traffic, no pools.  One 1024-thread block per CU shares the
-// 37-KB geometry table (variants: fewer waves with more ray slots each).  Results are the reference loop's: every
-// primitive whose conservative bound the ray enters before the best hit is tested exactly; image, live counts and
-// emitter hits equal every other kernel's bit for bit (tests/test_gpu_parity.py, tests/test_gpu_round3.py).
+// WALK, CELLS and BOUNDS interleave under one wave-uniform dispatcher: a buffer is drained whenever it holds 64
+// entries, so every stage but the walk itself runs on full waves whatever a single ray meets.  Nothing leaves the
+// wave: no barrier, no inter-wave traffic, no pools.  One 1024-thread block per CU shares the 37-KB geometry table
+// and the grid (variants: fewer waves with more ray slots each).  Results are the reference loop's: the cells are
+// filled with margins far above the walk's float error, so every primitive whose bound the ray enters is found, and
+// every candidate entered before the best hit is tested exactly; image, live counts and emitter hits equal every
+// other kernel's bit for bit (tests/test_gpu_parity.py, tests/test_gpu_round3.py).
 #include "pt_kernels.hpp"
 
 namespace ptk {
+
+#ifdef PT_CULL_STATS
+static __device__ unsigned long long g_phase_cycles[16];
+static __device__ unsigned long long g_wstats[32];
+// [0] FRESH groups [1] valid lanes [2] walk trips [3] walking lanes [4] (ray, cell) entries [5] CELLS chunks [6] lanes [7] -
+// [8] - [9] (ray, primitive) entries [10] BOUNDS cube chunks [11] lanes [12] BOUNDS sphere chunks [13] lanes [14] candidates
+// [15] overflowed / unwalked rays [16] TEST cube groups [17] lanes [18] TEST sphere groups [19] lanes [20] shaded [21] done
+// [22] requeued [23] requeued after a win [24] unwalked rays [25] bound tests of big primitives (lanes)
+__device__ __forceinline__ void wstat(int i, unsigned long long v) { if ((threadIdx.x & 63) == 0 && v) atomicAdd(&g_wstats[i], v); }
+#define PT_WSTAT(i, v) wstat((i), (unsigned long long)(v))
+#else
+#define PT_WSTAT(i, v) do { } while (0)
+#endif
 
 namespace {
 
@@ -43,9 +67,12 @@ enum : uint32_t { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_L0, F_L1, F_L2, F_L3
 // payload fields (SoA, stride R floats, global memory, per wave)
 enum : uint32_t { P_TX = 0, P_TY, P_TZ, P_PV, P_LEVEL, P_PX, P_PY, P_PZ, P_NX, P_NY, P_NZ };
 static_assert(P_NZ + 1 == kWPayload, "payload record");
+static_assert(100 * 4 + sizeof(GridArgs) <= kCtrlBytes, "the parked GridArgs must fit behind the survivors' counters in the control block");
 
 constexpr uint32_t kMetaHasHit = 1u << 27;
 constexpr uint32_t kListCap = 8;
+constexpr uint32_t kBufA = 128;        // (ray, cell) entries: a walk trip adds <= 64 to <= 63 waiting
+constexpr uint32_t kBufC = 192;        // (ray, primitive) entries, cubes from the bottom, spheres from the top: a CELLS trip adds <= 64 to <= 63 + 63
 
 // quantised conservative entry distance: floor(max(tn, 0) * qscale), 0..254 (255 would collide with the empty key 0xFFFF)
 __device__ __forceinline__ uint32_t quant_tn(float tn, float qscale) {
@@ -71,8 +98,8 @@ __device__ __forceinline__ uint32_t select_next(const uint32_t L[4], uint32_t qm
 
 }  // namespace
 
-template <int WAVES, int R, int PB>
-__global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, const GeomRec *__restrict__ geoms,
+template <int WAVES, int R>
+__global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, GridArgs ga, const GeomRec *__restrict__ geoms,
                                                         const MatRec *__restrict__ mats, const FaceFrame *__restrict__ frames) {
     constexpr uint32_t STK = (uint32_t)((R + 64 + 63) / 64 * 64);      // survivors' stack: at most 63 + R rays wait for their next bounce
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -86,23 +113,31 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, c
         park[0] = (uint32_t)pl; park[1] = (uint32_t)(pl >> 32); park[2] = (uint32_t)st; park[3] = (uint32_t)(st >> 32);
         park[4] = (uint32_t)a.cam.W; park[5] = (uint32_t)a.cam.row_offset; park[6] = a.cam.mW; park[7] = a.cam.shW;
         park[8] = a.cam.mS; park[9] = a.cam.shS;
+        *reinterpret_cast<GridArgs *>(ctrl + 100) = ga;    // the walk's set-up reads the grid's figures from here: the scalar file is full,
+    }                                                      // and a spilled scalar costs a lane read per use
+    // the grid blob goes behind the geometry table (stage_tables ends with the block's barrier)
+    const uint32_t tb = tables_bytes(a.G, a.M, true);
+    {
+        uint32_t *gdst = reinterpret_cast<uint32_t *>(smem + tb);
+        const uint32_t *gsrc = reinterpret_cast<const uint32_t *>(ga.blob);
+        for (uint32_t i = threadIdx.x; i < ga.blob_bytes / 4u; i += blockDim.x) gdst[i] = gsrc[i];
     }
     GeomRec *lg;
     MatRec *lm;
-    stage_tables(smem, geoms, a.G, mats, a.M, true, lg, lm, a.cluster_bytes);        // ends with __syncthreads()
-    const ClusterRec *cl = reinterpret_cast<const ClusterRec *>(lg + a.G);
-    const int nbc = a.nbc, nsc = a.nsc;
-    const unsigned char *members = reinterpret_cast<const unsigned char *>(cl + nbc + nsc);
-    const int nmem = nbc + nsc > 0 ? cl[nbc + nsc - 1].first + cl[nbc + nsc - 1].count : 0;      // analytic primitives (MESH objects without data are in no cluster)
+    stage_tables(smem, geoms, a.G, mats, a.M, true, lg, lm);
+    const uint32_t *cells = reinterpret_cast<const uint32_t *>(smem + tb);
+    const unsigned short *refs = reinterpret_cast<const unsigned short *>(cells + ga.ncells);
+    const unsigned char *bigs = reinterpret_cast<const unsigned char *>(refs + ((ga.nrefs + 1u) & ~1u));
+    const int nbig = (int)ga.nbig;
 
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     const uint32_t wslot = blockIdx.x * WAVES + wave;
     const uint32_t nwaves = gridDim.x * WAVES;
     const uint32_t D = pa.depth;
-    // the wave's LDS region: 12 slot fields x R | typed stacks of slot ids (cubes up, spheres down) | free list | pair buffer
-    uint32_t *wl = reinterpret_cast<uint32_t *>(smem + tables_bytes(a.G, a.M, true) + a.cluster_bytes) + (size_t)wave * (14u * R + PB);
+    // the wave's LDS region: 12 slot fields x R | typed stacks of slot ids (cubes up, spheres down) | free list | the two pair buffers
+    uint32_t *wl = reinterpret_cast<uint32_t *>(smem + tb + ga.blob_bytes) + (size_t)wave * (14u * R + kBufA + kBufC);
     float *wf = reinterpret_cast<float *>(wl);
-    uint32_t *xstack = wl + 12u * R, *freel = wl + 13u * R, *pairbuf = wl + 14u * R;
+    uint32_t *xstack = wl + 12u * R, *freel = wl + 13u * R, *bufA = wl + 14u * R, *bufC = bufA + kBufA;
     for (uint32_t i = lane; i < (uint32_t)R; i += 64u) freel[i] = i;
     uint32_t nfree = R;
 
@@ -134,11 +169,36 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, c
     if (pa.static_rounds == 0u && lane == 0) next_ticket = atomicAdd(pa.ticket + ctr * kTicketStride, 1u);
     uint32_t turns = 0u;
     const float kInf = 100000000000000000.0f;
+#ifdef PT_CULL_STATS
+    // phase clock of the analysis build: cycles between phase marks, summed per wave (0 schedule, 1 fresh load + big primitives,
+    // 2 walk, 3 cells, 4 bounds, 5 select, 6 test load + exact test, 7 next candidate + requeue, 8 shading, 9 survivors)
+    // (pinned: the scheduler may not move instructions across a mark, and the mark waits for the phase's LDS / scalar traffic;
+    // vector-memory latency shows where the value is used)
+    unsigned long long ph_acc[10] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    auto ph_now = [&]() -> unsigned long long {
+        unsigned long long t_;
+        __builtin_amdgcn_sched_barrier(0);
+        __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        return t_;
+    };
+    unsigned long long ph_t0 = ph_now();
+    int ph_cur = 0;
+#define PT_PHASE(i) do { const unsigned long long t1_ = ph_now(); ph_acc[ph_cur] += t1_ - ph_t0; ph_t0 = t1_; ph_cur = (i); } while (0)
+#else
+#define PT_PHASE(i) PT_MARK("phase" #i)
+#endif
     const float qscale = pa.qscale, slack_max = pa.slack_max;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
     for (;;) {
+        PT_PHASE(0);
+        // the scheduler's state is wave-uniform by construction; saying so keeps its arithmetic on the scalar unit
+        nbox = __builtin_amdgcn_readfirstlane(nbox); nsph = __builtin_amdgcn_readfirstlane(nsph); nfree = __builtin_amdgcn_readfirstlane(nfree);
+        sp = __builtin_amdgcn_readfirstlane(sp); jobpos = __builtin_amdgcn_readfirstlane(jobpos); jobend = __builtin_amdgcn_readfirstlane(jobend);
+        round = __builtin_amdgcn_readfirstlane(round); ctr = __builtin_amdgcn_readfirstlane(ctr); dry = __builtin_amdgcn_readfirstlane(dry);
+        turns = __builtin_amdgcn_readfirstlane(turns);
         if (++turns > pa.turn_limit) { if (lane == 0) *pa.error = 3u; break; }             // never reached; bounds a broken build
         int act;                                                                           // 0 FRESH from the stack, 3 FRESH camera rays, 1 TEST cubes, 2 TEST spheres
         if (nbox >= 64u) act = 1;
@@ -173,6 +233,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, c
 
         if (act == 0 || act == 3) {
             // ================================================================ FRESH
+            PT_PHASE(1);
             f3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(1.0f, 1.0f, 1.0f);
             uint32_t pv = 0u, level = 0u;
             bool valid;
@@ -204,9 +265,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, c
                     level = __float_as_uint(ring_ld(off, 10));
                 }
             }
-#ifdef PT_CULL_STATS
-            qstat(0, 1ull); qstat(1, (unsigned long long)__popcll(__ballot(valid)));
-#endif
+            PT_WSTAT(0, 1); PT_WSTAT(1, __popcll(__ballot(valid)));
             // a slot for every ray of the group
             const u64 vb = __ballot(valid);
             const uint32_t nv = (uint32_t)__popcll(vb);
@@ -216,130 +275,156 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, c
                 wf[F_OX * R + sid] = o.x; wf[F_OY * R + sid] = o.y; wf[F_OZ * R + sid] = o.z;
                 wf[F_DX * R + sid] = d.x; wf[F_DY * R + sid] = d.y; wf[F_DZ * R + sid] = d.z;
                 wl[F_L0 * R + sid] = 0xFFFFFFFFu; wl[F_L1 * R + sid] = 0xFFFFFFFFu; wl[F_L2 * R + sid] = 0xFFFFFFFFu; wl[F_L3 * R + sid] = 0xFFFFFFFFu;
-                wl[F_META * R + sid] = 0u;                                                 // candidate count while the pairs are expanded
                 pay_st(sid, P_TX, thr.x); pay_st(sid, P_TY, thr.y); pay_st(sid, P_TZ, thr.z);
                 pay_st(sid, P_PV, __uint_as_float(pv)); pay_st(sid, P_LEVEL, __uint_as_float(level));
             }
             nfree -= nv;
-            // ---------------------------------------------------------------- wave-uniform pass over the cluster boxes
             const CullRay cr = make_cull_ray(o, d);
-            uint32_t mB = 0u, mS = 0u;
-            for (int c = 0; c < nbc; ++c) {
+            // ---------------------------------------------------------------- the big primitives: every ray, wave-uniform index
+            uint32_t ncand0 = 0u;
+            for (int k = 0; k < nbig; ++k) {
+                const uint32_t p = (uint32_t)__builtin_amdgcn_readfirstlane((int)bigs[k]);
+                const GeomRec *g = lg + p;
                 float tn;
-                if (cull_box(cl[c].bmin, cl[c].bmax, cr, tn)) mB |= 1u << c;
+                bool keep;
+                if (__builtin_amdgcn_readfirstlane(g->type) == 1) keep = cull_box(g->bmin, g->bmax, cr, tn);
+                else keep = cull_sphere(g->bmin, g->bmax, cr, tn);
+                if (keep && valid) {
+                    if (ncand0 < kListCap) {
+                        unsigned short *l16 = reinterpret_cast<unsigned short *>(&wl[(F_L0 + (ncand0 >> 1)) * R + sid]) + (ncand0 & 1u);
+                        *l16 = (unsigned short)((quant_tn(tn, qscale) << 8) | p);
+                    }
+                    ncand0++;
+                }
             }
-            for (int c = 0; c < nsc; ++c) {
-                float tn;
-                if (cull_box(cl[nbc + c].bmin, cl[nbc + c].bmax, cr, tn)) mS |= 1u << c;
-            }
-            if (!valid) { mB = 0u; mS = 0u; }
-            // ---------------------------------------------------------------- (ray, cluster) pairs, dense
-            // pair index: all cube pairs in lane order, then all sphere pairs (exclusive prefix sums over the wave)
-            uint32_t cB = (uint32_t)__popc(mB), cS = (uint32_t)__popc(mS);
-            uint32_t nextB = cB, nextS = cS;
-#pragma unroll
-            for (int sft = 1; sft < 64; sft <<= 1) {                                       // inclusive scans
-                const uint32_t tb = __shfl_up(nextB, sft), ts = __shfl_up(nextS, sft);
-                if (lane >= (uint32_t)sft) { nextB += tb; nextS += ts; }
-            }
-            const uint32_t TB = __builtin_amdgcn_readlane(nextB, 63), TS = __builtin_amdgcn_readlane(nextS, 63);
-            nextB -= cB; nextS = nextS - cS + TB;                                          // exclusive; spheres follow the cubes
-            const uint32_t T = TB + TS;
+            PT_WSTAT(25, (unsigned long long)nbig * nv);
+            // ---------------------------------------------------------------- walk set-up
+            // Walked: finite rays that start within `reach` of the grid (the others overflow their list on purpose).
+            const GridArgs &lga = *reinterpret_cast<const GridArgs *>(ctrl + 100);
+            const bool sane = grid_walk_sane(lga, o, d);
+            if (valid && !sane) ncand0 = kListCap + 1u;
+            PT_WSTAT(24, __popcll(__ballot(valid && !sane)));
+            if (valid) wl[F_META * R + sid] = ncand0;                                      // candidate count while the pairs are worked off
+            GridWalk gw = grid_walk_begin(lga, o, d, cr.inv, valid && sane);
+            const uint32_t max_trips = (uint32_t)__builtin_amdgcn_readfirstlane(lga.n[0] + lga.n[1] + lga.n[2]) + 2u;     // a walk takes at most n_x + n_y + n_z - 2 steps
+            uint32_t trips = 0u;
+            // ---------------------------------------------------------------- WALK / CELLS / BOUNDS under one dispatcher
+            uint32_t nA = 0u, nCb = 0u, nCs = 0u;
+            bool walk_left = true;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                         // the slots are written before any pair lane reads them
             __builtin_amdgcn_wave_barrier();
-            for (uint32_t base = 0u; base < T; base += (uint32_t)PB) {
-                const uint32_t end = base + (uint32_t)PB;
-                while (mB != 0u && nextB < end) {                                          // cheap per-lane loops: one store per pair
-                    const uint32_t b = (uint32_t)__builtin_ctz(mB);
-                    mB &= mB - 1u;
-                    pairbuf[nextB - base] = (sid << 8) | b;
-                    nextB++;
-                }
-                while (mS != 0u && nextS < end) {
-                    const uint32_t b = (uint32_t)__builtin_ctz(mS);
-                    mS &= mS - 1u;
-                    pairbuf[nextS - base] = (sid << 8) | ((uint32_t)nbc + b);
-                    nextS++;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const uint32_t here = T - base < (uint32_t)PB ? T - base : (uint32_t)PB;
-                for (uint32_t c0 = 0u; c0 < here; c0 += 64u) {
-                    const uint32_t idx = base + c0 + lane;
-                    const bool pvalid = c0 + lane < here;
-                    const bool isb = idx < TB;
-                    uint32_t psid = 0u, pc = 0u;
+            for (;;) {
+                int op;                                                                    // 0 walk, 1 CELLS, 3 BOUNDS cubes, 4 BOUNDS spheres
+                if (nCb >= 64u) op = 3;
+                else if (nCs >= 64u) op = 4;
+                else if (nA >= 64u) op = 1;
+                else if (walk_left) op = 0;
+                else if (nA) op = 1;
+                else if (nCb) op = 3;
+                else if (nCs) op = 4;
+                else break;
+                if (op == 0) {
+                    // ------------------------------------------------------------ WALK: one cell per trip, until 64 entries wait
+                    PT_PHASE(2);
+                    for (;;) {
+                        const u64 wb = __ballot(gw.walking);
+                        if (wb == 0ull || trips >= max_trips) { walk_left = false; break; }
+                        trips++;
+                        PT_WSTAT(2, 1); PT_WSTAT(3, __popcll(wb));
+                        uint32_t rec = 0u;
+                        if (gw.walking) rec = cells[grid_walk_cell(gw)];
+                        const bool emit = (rec >> 16) != 0u;
+                        const u64 eb = __ballot(emit);
+                        if (emit) bufA[nA + wave_rank(eb)] = sid | ((rec & 0xFFFFu) << 8) | (gw.emask << 21);  // the cell's first reference
+                        nA += (uint32_t)__popcll(eb);
+                        PT_WSTAT(4, __popcll(eb));
+                        if (gw.walking) grid_walk_step(gw);
+                        if (nA >= 64u) break;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                } else if (op == 1) {
+                    // ------------------------------------------------------------ CELLS: the top 64 (ray, reference) entries, lane = one entry;
+                    // a new primitive goes on to BOUNDS, and unless the reference is its cell's last, the entry returns for the next one
+                    PT_PHASE(3);
+                    const uint32_t n = nA < 64u ? nA : 64u;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    uint32_t e = 0u, ref = 0x4000u;
+                    const bool evalid = lane < n;
+                    if (evalid) {
+                        e = bufA[nA - n + lane];
+                        ref = (uint32_t)refs[(e >> 8) & 0x1FFFu];
+                    }
+                    nA -= n;
+                    PT_WSTAT(5, 1); PT_WSTAT(6, n);
+                    const bool isnew = evalid && grid_ref_is_new(ref, e >> 21);
+                    const bool sph = (ref & 0x8000u) != 0u;
+                    const bool again = (ref & 0x4000u) == 0u;                              // (invalid lanes: `last` is set)
+                    const u64 bb = __ballot(isnew && !sph), sb = __ballot(isnew && sph), gb = __ballot(again);
+                    __builtin_amdgcn_wave_barrier();                                       // every entry is read before any is overwritten
+                    if (isnew) {
+                        const uint32_t pos = sph ? kBufC - 1u - (nCs + wave_rank(sb)) : nCb + wave_rank(bb);
+                        bufC[pos] = (e & 0xFFu) | ((ref & 0xFFu) << 8);
+                    }
+                    if (again) bufA[nA + wave_rank(gb)] = e + 0x100u;
+                    nCb += (uint32_t)__popcll(bb); nCs += (uint32_t)__popcll(sb); nA += (uint32_t)__popcll(gb);
+                    PT_WSTAT(9, __popcll(bb) + __popcll(sb));
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                } else {
+                    // ------------------------------------------------------------ BOUNDS: the top 64 (ray, primitive) entries of one type
+                    PT_PHASE(4);
+                    const bool isb = op == 3;
+                    const uint32_t have = isb ? nCb : nCs;
+                    const uint32_t n = have < 64u ? have : 64u;
+                    const bool pvalid = lane < n;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    uint32_t psid = 0u, pp = 0u;
                     f3 po = mk(0, 0, 0), pd = mk(0, 0, 1);
-                    int first = 0, count = 0;
                     if (pvalid) {
-                        const uint32_t e = pairbuf[c0 + lane];
-                        psid = e >> 8; pc = e & 0xFFu;
+                        const uint32_t e = bufC[isb ? have - n + lane : kBufC - 1u - (have - n + lane)];
+                        psid = e & 0xFFu; pp = e >> 8;
                         po = mk(wf[F_OX * R + psid], wf[F_OY * R + psid], wf[F_OZ * R + psid]);
                         pd = mk(wf[F_DX * R + psid], wf[F_DY * R + psid], wf[F_DZ * R + psid]);
-                        first = cl[pc].first; count = cl[pc].count;
                     }
-#ifdef PT_CULL_STATS
-                    qstat(2, 1ull); qstat(3, (unsigned long long)__popcll(__ballot(pvalid)));
-                    { unsigned long long mt = (unsigned long long)count; for (int sft = 32; sft > 0; sft >>= 1) mt += __shfl_down(mt, sft); qstat(13, mt); }
-                    { int mx = count; for (int sft = 32; sft > 0; sft >>= 1) { const int t = __shfl_down(mx, sft); mx = t > mx ? t : mx; } qstat(15, (unsigned long long)mx); }
-#endif
-                    const CullRay pr = make_cull_ray(po, pd);
-                    // members' own bounds: per-lane gather from the geometry table; candidates -> the ray's list
-                    auto append = [&](uint32_t p, float tn) {
+                    if (isb) nCb -= n; else nCs -= n;
+                    PT_WSTAT(isb ? 10 : 12, 1); PT_WSTAT(isb ? 11 : 13, n);
+                    const GeomRec *g = lg + pp;                                            // per-lane gather from the geometry table
+                    float tn = 0.0f;
+                    bool keep;
+                    if (isb) { const CullRay pr = make_cull_ray(po, pd); keep = cull_box(g->bmin, g->bmax, pr, tn); }
+                    else { CullRay pr; pr.o = po; pr.d = pd; pr.inv = pd; pr.noi = pd; keep = cull_sphere(g->bmin, g->bmax, pr, tn); }
+                    if (pvalid && keep) {
                         const uint32_t pos = atomicAdd(&wl[F_META * R + psid], 1u);
 #ifdef PT_CULL_STATS
-                        atomicAdd(&g_cull_stats[10], 1ull);
+                        atomicAdd(&g_wstats[14], 1ull);
 #endif
                         if (pos < kListCap) {
                             unsigned short *l16 = reinterpret_cast<unsigned short *>(&wl[(F_L0 + (pos >> 1)) * R + psid]) + (pos & 1u);
-                            *l16 = (unsigned short)((quant_tn(tn, qscale) << 8) | p);
-                        }
-                    };
-                    if (__any(pvalid && isb)) {
-                        if (pvalid && isb) {
-#pragma unroll 1
-                            for (int k = 0; k < count; ++k) {
-                                const uint32_t p = members[first + k];
-                                const GeomRec *g = lg + p;
-                                float tn;
-                                if (cull_box(g->bmin, g->bmax, pr, tn)) append(p, tn);
-                            }
+                            *l16 = (unsigned short)((quant_tn(tn, qscale) << 8) | pp);
                         }
                     }
-                    if (__any(pvalid && !isb)) {
-                        if (pvalid && !isb) {
-#pragma unroll 1
-                            for (int k = 0; k < count; ++k) {
-                                const uint32_t p = members[first + k];
-                                const GeomRec *g = lg + p;
-                                float tn;
-                                if (cull_sphere(g->bmin, g->bmax, pr, tn)) append(p, tn);
-                            }
-                        }
-                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                     // the pair buffer is free again, the lists are written
-                __builtin_amdgcn_wave_barrier();
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             // ---------------------------------------------------------------- SELECT: nearest candidate first
+            PT_PHASE(5);
             bool queued = false, tobox = false;
             const uint32_t ncand = valid ? wl[F_META * R + sid] : 0u;
-            // Rays whose list overflowed (rare: 2 in 10 000 on configs[3]) take the reference loop itself; its winner is then
-            // confirmed by one exact test in a TEST group.  A few of them: one ray at a time on the WHOLE wave, every lane
-            // testing G / 64 primitives (cubes first, in the order of the member table) + a min-reduction with the
-            // reference's tie rule -- a lane alone would keep the wave waiting for G exact tests.  Many: the per-lane loop.
+            // Rays whose list overflowed (rare: 2 in 10 000 on configs[3]) or that were not walked take the reference loop itself; its
+            // winner is then confirmed by one exact test in a TEST group.  A few of them: one ray at a time on the WHOLE wave, every
+            // lane testing G / 64 primitives + a min-reduction with the reference's tie rule -- a lane alone would keep the wave
+            // waiting for G exact tests.  Many: the per-lane loop.
             int ovhit = -1;
             {
                 const bool ov = ncand > kListCap;
                 const u64 ovb = __ballot(ov);
-#ifdef PT_CULL_STATS
-                qstat(11, (unsigned long long)__popcll(ovb));
-#endif
+                PT_WSTAT(15, __popcll(ovb));
                 if (ovb) {
                     if (__popcll(ovb) >= 12) {
-                        if (ov) { float tb; f3 P, N; ovhit = nearest_hit(lg, a.G, o, d, tb, P, N); }
+                        if (ov) { float tb2; f3 P, N; ovhit = nearest_hit(lg, a.G, o, d, tb2, P, N); }
                     } else {
                         u64 m = ovb;
                         while (m) {
@@ -349,15 +434,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, c
                             const f3 dd = mk(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
                             float bd = kInf;
                             int bh = -1;
-                            for (int k = (int)lane; k < nmem; k += 64) {
-                                const int p = (int)members[k];               // every analytic primitive once: cubes, then spheres
-                                const GeomRec *g = lg + p;
-                                const bool pb = g->type == 1;
+                            for (int k = (int)lane; k < a.G; k += 64) {
+                                const GeomRec *g = lg + k;
+                                const int ty = g->type;
+                                const bool pb = ty == 1, psph = ty == 0;
                                 float depth = -1.0f;
                                 f3 P, N;
                                 if (__any(pb)) { if (pb) depth = box_test(g->inv, g->xf, g->inside_hits, oo, dd, P, N); }
-                                if (__any(!pb)) { if (!pb) depth = sphere_test(g->inv, g->xf, oo, dd, P, N); }
-                                if (depth > -PT_EPSILON && (depth < bd || (depth == bd && p < bh))) { bd = depth; bh = p; }
+                                if (__any(psph)) { if (psph) depth = sphere_test(g->inv, g->xf, oo, dd, P, N); }
+                                if (depth > -PT_EPSILON && (depth < bd || (depth == bd && k < bh))) { bd = depth; bh = k; }
                             }
 #pragma unroll
                             for (int sft = 32; sft > 0; sft >>= 1) {             // nearest wins, ties to the lower index
@@ -409,15 +494,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, c
         }
 
         // ==================================================================== TEST (one type per group, any levels)
+        PT_PHASE(6);
         const bool isb = act == 1;
         const uint32_t have = isb ? nbox : nsph;
         const uint32_t cnt = have < 64u ? have : 64u;
         const bool valid = lane < cnt;
         const uint32_t qpos = isb ? (have - cnt + lane) : ((uint32_t)R - 1u - (have - cnt + lane));
         if (isb) nbox -= cnt; else nsph -= cnt;
-#ifdef PT_CULL_STATS
-        qstat(isb ? 4 : 6, 1ull); qstat(isb ? 5 : 7, (unsigned long long)cnt);
-#endif
+        PT_WSTAT(isb ? 16 : 18, 1); PT_WSTAT(isb ? 17 : 19, cnt);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                // payload stores of earlier groups have landed ...
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");                // ... before they are read back through the same L1
@@ -463,6 +547,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, c
             if (won) { best = depth; hit = j; P = p; N = n; face = fc; has_hit = true; }
         }
         // the next candidate that could still win or tie: key distance not beyond the best hit (conservative: one step of slack)
+        PT_PHASE(7);
         uint32_t npos = 0u;
         uint32_t qmax = 254u;
         if (has_hit) {
@@ -485,11 +570,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, c
             }
             nbx = lg[nid].type == 1;
         }
-#ifdef PT_CULL_STATS
-        qstat(8, (unsigned long long)__popcll(__ballot(done && has_hit))); qstat(9, (unsigned long long)__popcll(__ballot(done)));
-        qstat(12, (unsigned long long)__popcll(__ballot(more))); qstat(14, (unsigned long long)__popcll(__ballot(more && won)));
-#endif
+        PT_WSTAT(20, __popcll(__ballot(done && has_hit))); PT_WSTAT(21, __popcll(__ballot(done)));
+        PT_WSTAT(22, __popcll(__ballot(more))); PT_WSTAT(23, __popcll(__ballot(more && won)));
         // ---------------------------------------------------------------- shade the finished rays that hit something
+        PT_PHASE(8);
         bool alive = false;
         if (done && has_hit) {
             const uint32_t slot = a.batch > 1u ? pv >> 24 : 0u, pixel = pv & a.pix_mask;
@@ -526,6 +610,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, c
         }
         if (alive) atomicAdd(&lsurv[level + 1u], 1u);
         // ---------------------------------------------------------------- requeue / free / survivors
+        PT_PHASE(9);
         {
             const u64 bb = __ballot(more && nbx), sb = __ballot(more && !nbx), fb = __ballot(done);
             if (more) {
@@ -558,6 +643,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, c
         }
     }
 
+#ifdef PT_CULL_STATS
+    PT_PHASE(0);
+    if (lane == 0) for (int i = 0; i < 10; ++i) atomicAdd(&g_phase_cycles[i], ph_acc[i]);
+#endif
     for (int sft = 32; sft > 0; sft >>= 1) emitted += __shfl_down(emitted, sft);
     if (lane == 0 && emitted) atomicAdd(&ctrl[1], emitted);
     __syncthreads();
@@ -567,22 +656,22 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, c
 
 // ------------------------------------------------------------------ host side ---------
 namespace {
-struct WideShape { int waves, slots, pairbuf; };
-// variant -> block shape.  One block per CU; the waves share the CU's LDS: tables + waves x (14 x slots + pairbuf) dwords
-constexpr WideShape kShapes[3] = {{16, 120, 128}, {12, 168, 128}, {8, 256, 256}};
+struct WideShape { int waves, slots; };
+// variant -> block shape.  One block per CU; the waves share the CU's LDS: tables + grid + waves x (14 x slots + the two pair buffers) dwords
+constexpr WideShape kShapes[3] = {{16, 104}, {12, 144}, {8, 232}};
 
-template <int WAVES, int R, int PB>
-const void *wide_fn() { return reinterpret_cast<const void *>(&k_path_w<WAVES, R, PB>); }
+template <int WAVES, int R>
+const void *wide_fn() { return reinterpret_cast<const void *>(&k_path_w<WAVES, R>); }
 const void *wide_fn_of(int v) {
-    return v == 1 ? wide_fn<12, 168, 128>() : v == 2 ? wide_fn<8, 256, 256>() : wide_fn<16, 120, 128>();
+    return v == 1 ? wide_fn<12, 144>() : v == 2 ? wide_fn<8, 232>() : wide_fn<16, 104>();
 }
 int clamp_variant(int v) { return v < 0 || v > 2 ? 0 : v; }
 }  // namespace
 
-hipError_t wide_setup(int variant, int G, int M, uint32_t cluster_bytes, WideLayout *out) {
+hipError_t wide_setup(int variant, int G, int M, uint32_t grid_bytes, WideLayout *out) {
     const int v = clamp_variant(variant);
     const WideShape s = kShapes[v];
-    const uint32_t lds = tables_bytes(G, M, true) + cluster_bytes + (uint32_t)s.waves * (14u * (uint32_t)s.slots + (uint32_t)s.pairbuf) * 4u;
+    const uint32_t lds = tables_bytes(G, M, true) + grid_bytes + (uint32_t)s.waves * (14u * (uint32_t)s.slots + kBufA + kBufC) * 4u;
     out->waves_per_block = (uint32_t)s.waves;
     out->slots_per_wave = (uint32_t)s.slots;
     out->stack_slots = (uint32_t)((s.slots + 64 + 63) / 64 * 64);
@@ -591,20 +680,23 @@ hipError_t wide_setup(int variant, int G, int M, uint32_t cluster_bytes, WideLay
     return hipFuncSetAttribute(wide_fn_of(v), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-void wide_launch(int variant, int grid, uint32_t lds, hipStream_t st, const SegArgs &a, const PathArgs &pa,
+void wide_launch(int variant, int grid, uint32_t lds, hipStream_t st, const SegArgs &a, const PathArgs &pa, const GridArgs &ga,
                  const GeomRec *g, const MatRec *m, const FaceFrame *frames) {
     switch (clamp_variant(variant)) {
-    case 1: hipLaunchKernelGGL((k_path_w<12, 168, 128>), dim3(grid), dim3(12 * 64), lds, st, a, pa, g, m, frames); break;
-    case 2: hipLaunchKernelGGL((k_path_w<8, 256, 256>), dim3(grid), dim3(8 * 64), lds, st, a, pa, g, m, frames); break;
-    default: hipLaunchKernelGGL((k_path_w<16, 120, 128>), dim3(grid), dim3(16 * 64), lds, st, a, pa, g, m, frames); break;
+    case 1: hipLaunchKernelGGL((k_path_w<12, 144>), dim3(grid), dim3(12 * 64), lds, st, a, pa, ga, g, m, frames); break;
+    case 2: hipLaunchKernelGGL((k_path_w<8, 232>), dim3(grid), dim3(8 * 64), lds, st, a, pa, ga, g, m, frames); break;
+    default: hipLaunchKernelGGL((k_path_w<16, 104>), dim3(grid), dim3(16 * 64), lds, st, a, pa, ga, g, m, frames); break;
     }
 }
 
 #ifdef PT_CULL_STATS
-void cull_stats_wide(unsigned long long *acc16) {
-    unsigned long long v[16];
-    if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_cull_stats), sizeof v) == hipSuccess) for (int i = 0; i < 16; ++i) acc16[i] += v[i];
+void phase_cycles_wide(unsigned long long *out16) {
+    (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_cycles), 16 * sizeof(unsigned long long));
 }
+void stats_wide(unsigned long long *out32) {
+    (void)hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_wstats), 32 * sizeof(unsigned long long));
+}
+void cull_stats_wide(unsigned long long *) {}
 #endif
 
 }  // namespace ptk

@@ -11,8 +11,8 @@
 //                                  candidate type, one launch per bounce
 //   pt_k_path.hip   k_path_q       ordering = 2, <= 32 primitives: whole paths on the typed work queues, one launch
 //                                  per group of iterations (what bench.py, the adaptor and ptrender run)
-//   pt_k_wide.hip   k_path_w       ordering = 2, 33..256 primitives: whole paths, dense (ray, cluster) pairs and
-//                                  type-pure exact tests on full waves
+//   pt_k_wide.hip   k_path_w       ordering = 2, 33..256 primitives: whole paths; a grid walk feeds dense (ray, cell) and
+//                                  (ray, primitive) pairs, type-pure exact tests on full waves
 //   pt_k_misc.hip   k_fold, k_flat (the reference kernel as shipped + primary-hit hook), k_display, KAT kernels
 //   pt_api.hip      contexts, scene upload, the C ABI of include/ptmi355.h
 //
@@ -272,9 +272,6 @@ __device__ __forceinline__ int nearest_hit_culled(const GeomRec *lg, const GeomR
 // bounds, so a primitive the exact test can hit is always reached.
 #ifndef PT_CLUSTER
 #define PT_CLUSTER 4                                  // preferred members per cluster; the host grows it until <= 64 clusters
-#endif
-#ifndef PT_CLUSTER_PATHW
-#define PT_CLUSTER_PATHW 5                            // k_path_w: measured best on configs[3] (5: 1.08, 6: 1.12, 8: 1.16, 12: 1.24 ms/step, profiles/r03a_*)
 #endif
 constexpr int kClusterMax = 16;
 struct __attribute__((aligned(16))) ClusterRec {      // lives behind the geometry table in LDS, cube clusters first
@@ -651,6 +648,105 @@ struct PathArgs {
 };
 constexpr uint32_t kWPayload = 11;   // k_path_w: floats per ray slot parked in global memory (throughput, pixel word, level, best hit's P and N)
 
+// k_path_w's spatial index: a uniform grid over the SMALL analytic primitives (host: build_grid, pt_api.hip).  A ray
+// walks the cells it crosses (3D-DDA) and only the primitives listed there have their own bounds tested; primitives
+// that would be listed in more than kGridBigCells cells (walls, floors) wait in a short list every ray tests.
+// Blob, staged in LDS behind the geometry table: cells[ncells] (first ref | count << 16), refs[nrefs] (16 bits each),
+// big[nbig] (primitive ids).  A ref is the primitive id | flags << 8: bits 0..2 this cell is the LOWEST cell of the
+// primitive's cell range on x, y, z; bits 3..5 the HIGHEST; bit 6 it is the cell's last reference; bit 7 the primitive is a sphere.
+// The flags make the walk list every primitive ONCE without any arithmetic on distances: the cells of a ray inside a
+// primitive's (box-shaped) cell range are consecutive, so the primitive is new in a cell exactly when the step into
+// that cell crossed the range's boundary on one of the axes stepped -- or when the cell is the ray's first.
+constexpr int kGridBigCells = 27;
+constexpr uint32_t kGridMaxCells = 8192;            // 13 bits of a pair entry
+struct GridArgs {
+    float gmin[3];                   // lower corner
+    float h[3], inv_h[3];            // cell size per axis and its reciprocal
+    int n[3];                        // cells per axis
+    float centre[3], reach;          // a ray starting farther than `reach` from the centre on any axis is not walked (its
+                                     //   float error would exceed the margin the cells were filled with): reference loop
+    uint32_t ncells, nrefs, nbig;
+    uint32_t blob_bytes;             // multiple of 16
+    const unsigned char *blob;       // device copy
+};
+
+// One ray's walk through the grid: the state a lane keeps, how it starts and how it steps.  Host-callable: the grid
+// probe of the CPU-side tests (pt_debug_grid_probe) runs these very functions over the host copy of the blob.
+// `inv` is 1/d per axis with |d| clamped away from zero (make_cull_ray on the device); its SIGN says which way the
+// axis steps.  The distance to the k-th boundary of an axis is fma(k, dt, t0) -- one rounding whatever k is, no
+// accumulated error -- and the cell's address is rebuilt from the three step counters the same way (exact: small integers).
+struct GridWalk {
+    float tx, ty, tz;                // distance to the next cell boundary per axis
+    float kx, ky, kz;                // steps taken per axis (integer-valued)
+    float t0x, t0y, t0z, dtx, dty, dtz;   // tx = fma(kx, dtx, t0x)
+    float kmx, kmy, kmz;             // steps the grid allows per axis: one more leaves it
+    float c0, scx, scy, scz;         // linear cell index = c0 + kx * scx + ky * scy + kz * scz (signed strides)
+    uint32_t selmask;                // the reference flags that mean "new" per axis: stepping up meets a cell range at its lowest
+                                     //   cell (bits 0..2), stepping down at its highest (bits 3..5)
+    uint32_t emask;                  // flags that make a reference new in the current cell; bit 6: the ray's first cell (all are new)
+    bool walking;
+};
+
+// `wanted` rays only; the part of the ray inside the grid's box is [t0, t1] (margins on both sides); none: nothing to walk
+__host__ __device__ __forceinline__ GridWalk grid_walk_begin(const GridArgs &ga, f3 o, f3 d, f3 inv, bool wanted) {
+    GridWalk w;
+    const float gx0 = ga.gmin[0], gy0 = ga.gmin[1], gz0 = ga.gmin[2], hx = ga.h[0], hy = ga.h[1], hz = ga.h[2];
+    const int nx = ga.n[0], ny = ga.n[1], nz = ga.n[2];
+    const float gx1 = __builtin_fmaf((float)nx, hx, gx0), gy1 = __builtin_fmaf((float)ny, hy, gy0), gz1 = __builtin_fmaf((float)nz, hz, gz0);
+    const float ax0 = (gx0 - o.x) * inv.x, ax1 = (gx1 - o.x) * inv.x;
+    const float ay0 = (gy0 - o.y) * inv.y, ay1 = (gy1 - o.y) * inv.y;
+    const float az0 = (gz0 - o.z) * inv.z, az1 = (gz1 - o.z) * inv.z;
+    const float t0 = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fmaxf(fminf(az0, az1), 0.0f));
+    const float t1 = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fmaxf(az0, az1));
+    const float t0m = t0 - __builtin_fmaf(fabsf(t0), 2e-5f, 1e-30f), t1p = t1 + __builtin_fmaf(fabsf(t1), 2e-5f, 1e-30f);
+    w.walking = wanted && !(t0m > t1p);
+    const f3 ps = mk(__builtin_fmaf(d.x, t0, o.x), __builtin_fmaf(d.y, t0, o.y), __builtin_fmaf(d.z, t0, o.z));
+    const bool ngx = inv.x < 0.0f, ngy = inv.y < 0.0f, ngz = inv.z < 0.0f;
+    int ix = (int)floorf((ps.x - gx0) * ga.inv_h[0]), iy = (int)floorf((ps.y - gy0) * ga.inv_h[1]), iz = (int)floorf((ps.z - gz0) * ga.inv_h[2]);
+    ix = ix < 0 ? 0 : (ix > nx - 1 ? nx - 1 : ix);
+    iy = iy < 0 ? 0 : (iy > ny - 1 ? ny - 1 : iy);
+    iz = iz < 0 ? 0 : (iz > nz - 1 ? nz - 1 : iz);
+    w.c0 = (float)(ix + nx * (iy + ny * iz));
+    w.scx = ngx ? -1.0f : 1.0f; w.scy = (float)(ngy ? -nx : nx); w.scz = (float)(ngz ? -(nx * ny) : nx * ny);
+    w.kmx = (float)(ngx ? ix : nx - 1 - ix); w.kmy = (float)(ngy ? iy : ny - 1 - iy); w.kmz = (float)(ngz ? iz : nz - 1 - iz);
+    w.kx = 0.0f; w.ky = 0.0f; w.kz = 0.0f;
+    // first boundary ahead per axis, then one cell size further per step
+    w.t0x = (__builtin_fmaf((float)(ngx ? ix : ix + 1), hx, gx0) - o.x) * inv.x;
+    w.t0y = (__builtin_fmaf((float)(ngy ? iy : iy + 1), hy, gy0) - o.y) * inv.y;
+    w.t0z = (__builtin_fmaf((float)(ngz ? iz : iz + 1), hz, gz0) - o.z) * inv.z;
+    w.dtx = hx * fabsf(inv.x); w.dty = hy * fabsf(inv.y); w.dtz = hz * fabsf(inv.z);
+    w.tx = w.t0x; w.ty = w.t0y; w.tz = w.t0z;
+    w.selmask = (ngx ? 8u : 1u) | (ngy ? 16u : 2u) | (ngz ? 32u : 4u);
+    w.emask = 0x40u;
+    return w;
+}
+
+__host__ __device__ __forceinline__ uint32_t grid_walk_cell(const GridWalk &w) {
+    return (uint32_t)__builtin_fmaf(w.kz, w.scz, __builtin_fmaf(w.ky, w.scy, __builtin_fmaf(w.kx, w.scx, w.c0)));
+}
+
+// to the next cell: the axis whose boundary comes first; a tie steps on every tied axis at once (the cells skipped touch
+// the ray in a point only, and whatever lies that close to it is listed in the cell entered as well: the margin).
+// Branch-free; once the ray has left the grid (`walking` false) the rest of the state is meaningless.
+__host__ __device__ __forceinline__ void grid_walk_step(GridWalk &w) {
+    const float tm = fminf(fminf(w.tx, w.ty), w.tz);
+    const bool sx = w.tx <= tm, sy = w.ty <= tm, sz = w.tz <= tm;
+    const bool out = (sx & (w.kx == w.kmx)) | (sy & (w.ky == w.kmy)) | (sz & (w.kz == w.kmz));
+    w.kx += sx ? 1.0f : 0.0f; w.ky += sy ? 1.0f : 0.0f; w.kz += sz ? 1.0f : 0.0f;
+    w.tx = __builtin_fmaf(w.kx, w.dtx, w.t0x); w.ty = __builtin_fmaf(w.ky, w.dty, w.t0y); w.tz = __builtin_fmaf(w.kz, w.dtz, w.t0z);
+    w.emask = w.selmask & ((sx ? 9u : 0u) | (sy ? 18u : 0u) | (sz ? 36u : 0u));
+    w.walking = w.walking & !out;
+}
+
+// a reference (GridArgs) is new to a ray in a cell entered with `emask`
+__host__ __device__ __forceinline__ bool grid_ref_is_new(uint32_t ref, uint32_t emask) { return ((((ref >> 8) & 0x3Fu) | 0x40u) & emask) != 0u; }
+
+// may the ray be walked at all?  finite, a direction of sane length, the origin within `reach` of the grid's centre
+__host__ __device__ __forceinline__ bool grid_walk_sane(const GridArgs &ga, f3 o, f3 d) {
+    return fabsf(o.x - ga.centre[0]) <= ga.reach && fabsf(o.y - ga.centre[1]) <= ga.reach && fabsf(o.z - ga.centre[2]) <= ga.reach &&
+           fabsf(d.x) <= 4.0f && fabsf(d.y) <= 4.0f && fabsf(d.z) <= 4.0f;
+}
+
 __host__ __device__ inline uint32_t p_cursor_offset(int G, int M) { return q_lds_offset(G, M); }
 __host__ __device__ inline uint32_t p_queue_offset(int G, int M) { return p_cursor_offset(G, M); }
 __host__ __device__ inline uint32_t p_lds_bytes(int G, int M) { return p_queue_offset(G, M) + (uint32_t)kWaves * kPCap * kPFields * 4u; }
@@ -696,8 +792,8 @@ void path_launch(bool mesh, int grid, uint32_t lds_bytes, hipStream_t stream, co
 
 // k_path_w (pt_k_wide.hip): `variant` picks the block shape; the layout says what it needs
 struct WideLayout { uint32_t waves_per_block, slots_per_wave, stack_slots, lds_bytes; };
-hipError_t wide_setup(int variant, int G, int M, uint32_t cluster_bytes, WideLayout *out);
-void wide_launch(int variant, int grid, uint32_t lds_bytes, hipStream_t stream, const SegArgs &a, const PathArgs &pa,
+hipError_t wide_setup(int variant, int G, int M, uint32_t grid_bytes, WideLayout *out);
+void wide_launch(int variant, int grid, uint32_t lds_bytes, hipStream_t stream, const SegArgs &a, const PathArgs &pa, const GridArgs &ga,
                  const GeomRec *geoms, const MatRec *mats, const FaceFrame *frames);
 
 void fold_launch(hipStream_t stream, const FoldArgs &f);
@@ -712,6 +808,8 @@ void cull_stats_seg(unsigned long long *acc16);      // analysis builds: every f
 void cull_stats_queue(unsigned long long *acc16);
 void cull_stats_path(unsigned long long *acc16);
 void cull_stats_wide(unsigned long long *acc16);
+void phase_cycles_wide(unsigned long long *out16);     // k_path_w: cycles per phase, summed over the waves
+void stats_wide(unsigned long long *out32);            // k_path_w: stage statistics (indices: pt_k_wide.hip)
 #endif
 
 }  // namespace ptk

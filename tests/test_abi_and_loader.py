@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(pkg):
         assert hasattr(L, name), "libptmi355.so does not export %s" % name
     assert sorted(pkg.EXPORTS) == declared
     version = int(re.search(r"#define\s+PTMI355_ABI_VERSION\s+(\d+)", hdr).group(1))
-    assert pkg.lib().pt_abi_version() == version == 7
+    assert pkg.lib().pt_abi_version() == version == 8
 
 
 def test_pod_sizes_match_reference_structs(pkg):

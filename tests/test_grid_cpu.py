@@ -1,0 +1,182 @@
+"""The spatial index of the whole-path kernel for 33..256 primitives (k_path_w), checked WITHOUT a device.
+
+`pt_debug_grid_probe` builds the uniform grid exactly as `pt_upload_scene` does and walks rays on the host with the
+kernel's own walk functions and reference flags (csrc/pt_kernels.hpp: grid_walk_begin / grid_walk_step).  What the
+kernel needs from the index, and what is asserted here against a double-precision slab test of every primitive's
+geometric bounding box:
+
+  * complete: a primitive whose box the ray meets (t >= 0) is listed for the ray -- by a cell of the walk or by the
+    list of big primitives (the exact test can only hit inside that box, so nothing the reference loop
+    /root/reference/src/raytraceKernel.cu:134-153 would hit is lost);
+  * once: no primitive is listed twice for a ray (a duplicate would waste a slot of the 8-entry candidate list);
+  * bounded: a walk ends within n_x + n_y + n_z cells.
+
+Ray families: random interior rays, camera rays, axis-parallel rays (zero direction components, origins ON cell
+boundaries), rays aimed at the corners and edges of primitive boxes (grazing), rays from outside and far away, the
+non-finite ones; at the scene's own scale and at 0.05 x, 37 x and 1000 x (as tests/test_gpu_parity.py renders them)."""
+import numpy as np
+import pytest
+
+import orc
+from conftest import load_package
+from gpu_common import to_product
+
+
+def _boxes(geoms):
+    """geometric world AABB of every analytic primitive: cube = its 8 corners, sphere (ellipsoid) = centre +- 0.5 |row|"""
+    lo, hi, ids = [], [], []
+    for i, g in enumerate(geoms):
+        if g.type not in (0, 1):
+            continue
+        m = np.array([g.transform[k] for k in range(12)], dtype=np.float64).reshape(3, 4)
+        c = m[:, 3]
+        if g.type == 1:
+            ext = 0.5 * np.abs(m[:, :3]).sum(1)
+        else:
+            ext = 0.5 * np.sqrt((m[:, :3] ** 2).sum(1))
+        lo.append(c - ext); hi.append(c + ext); ids.append(i)
+    return np.array(lo), np.array(hi), np.array(ids)
+
+
+def _meets(rays, lo, hi):
+    """[n, P] bool: the ray (double precision) meets the box at some t >= 0; rays with a zero component handled by limits"""
+    o = rays[:, None, :3].astype(np.float64); d = rays[:, None, 3:].astype(np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t0 = (lo[None] - o) / d; t1 = (hi[None] - o) / d
+    tn = np.minimum(t0, t1); tf = np.maximum(t0, t1)
+    par = d == 0.0                                         # parallel to the slab: inside it or never
+    inside = (o >= lo[None]) & (o <= hi[None])
+    tn = np.where(par, np.where(inside, -np.inf, np.inf), tn)
+    tf = np.where(par, np.where(inside, np.inf, -np.inf), tf)
+    enter = tn.max(2); leave = tf.min(2)
+    return (enter <= leave) & (leave >= 0.0)
+
+
+def _scaled(name, factor):
+    import json, os
+    if factor == 1.0:
+        return orc.load_golden_scene(name)
+    gold = json.load(open(os.path.join(orc.GOLD, "ref_scene_%s.json" % name)))
+    base = orc.load_golden_scene(name)
+    geoms = []
+    xf, inv = np.zeros(16, np.float32), np.zeros(16, np.float32)
+    for o, g0 in zip(gold["objects"], base.geoms):
+        fr = o["frames"][0]
+        t = [orc.f32_from_bits(v) * factor for v in fr["translation"]]
+        r = [orc.f32_from_bits(v) for v in fr["rotation"]]
+        s = [orc.f32_from_bits(v) * factor for v in fr["scale"]]
+        orc.lib().orc_build_transform(orc.vec3(*t), orc.vec3(*r), orc.vec3(*s), orc.fptr(xf), orc.fptr(inv))
+        g = orc.Geom()
+        g.type, g.materialid = g0.type, g0.materialid
+        for k in range(16):
+            g.transform[k] = float(xf[k]); g.inverseTransform[k] = float(inv[k])
+        geoms.append(g)
+    return orc.Scene(geoms, base.materials, base.camera)
+
+
+def _ray_families(lo, hi, rng, n):
+    blo, bhi = lo.min(0), hi.max(0)
+    size = (bhi - blo).max()
+    fam = {}
+    o = rng.uniform(blo, bhi, (n, 3)); d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    fam["interior"] = np.concatenate([o, d], 1)
+    # from outside, towards a random point of the scene
+    o = blo + (bhi - blo) * rng.uniform(-1.5, 2.5, (n, 3)); tgt = rng.uniform(blo, bhi, (n, 3)); d = tgt - o; d /= np.linalg.norm(d, axis=1, keepdims=True)
+    fam["outside"] = np.concatenate([o, d], 1)
+    # axis-parallel and planar directions (exact zeros), origins snapped to a coarse lattice so that many lie on cell boundaries
+    o = rng.uniform(blo, bhi, (n, 3)); o = np.round((o - blo) / size * 32) / 32 * size + blo
+    d = rng.normal(size=(n, 3)); z = rng.integers(0, 7, n)
+    for k in range(3):
+        d[(z >> k) & 1 == 1, k] = 0.0
+    d[(d == 0).all(1)] = [1.0, 0.0, 0.0]
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    fam["axis"] = np.concatenate([o, d], 1)
+    # grazing: aimed at box corners / points on box edges, from random origins, with perturbations of a few ulp
+    pick = rng.integers(0, len(lo), n); cs = rng.integers(0, 2, (n, 3)).astype(bool)
+    corner = np.where(cs, hi[pick], lo[pick])
+    edge = rng.integers(0, 3, n); w = rng.uniform(0, 1, n)
+    for k in range(3):
+        sel = edge == k
+        corner[sel, k] = lo[pick[sel], k] + w[sel] * (hi[pick[sel], k] - lo[pick[sel], k])
+    o = rng.uniform(blo, bhi, (n, 3)); d = corner - o
+    d *= 1.0 + rng.uniform(-3e-7, 3e-7, (n, 3))
+    nrm = np.linalg.norm(d, axis=1, keepdims=True); keep = nrm[:, 0] > 1e-6 * size
+    fam["grazing"] = np.concatenate([o, d / np.where(nrm > 0, nrm, 1)], 1)[keep]
+    # far away (beyond the reach of the walk: the kernel takes the reference loop) and non-finite
+    o = blo + (bhi - blo) * rng.uniform(-40, 40, (n // 4, 3)); tgt = rng.uniform(blo, bhi, (n // 4, 3)); d = tgt - o; d /= np.linalg.norm(d, axis=1, keepdims=True)
+    far = np.concatenate([o, d], 1)
+    bad = fam["interior"][:8].copy(); bad[0, 0] = np.nan; bad[1, 4] = np.nan; bad[2, 3] = np.inf; bad[3, 1] = -np.inf; bad[4, 3:] = 0.0
+    fam["far_and_bad"] = np.concatenate([far, bad], 0)
+    return {k: v.astype(np.float32) for k, v in fam.items()}
+
+
+@pytest.mark.parametrize("density", [0, 1, 16])
+@pytest.mark.parametrize("factor", [1.0, 0.05, 37.0, 1000.0])
+def test_grid_walk_lists_every_primitive_a_ray_meets_exactly_once(pt, factor, density):
+    sc = _scaled("random256", factor)
+    geoms, _, _ = to_product(sc)
+    lo, hi, ids = _boxes(sc.geoms)
+    rng = np.random.default_rng(565 + density)
+    total = 0
+    for name, rays in _ray_families(lo, hi, rng, 6000).items():
+        sets, info = pt.grid_probe(geoms, rays, density)
+        assert info["duplicates"] == 0, (name, info)
+        assert info["longest_walk"] <= info["nx"] + info["ny"] + info["nz"], (name, info)
+        finite = np.isfinite(rays).all(1)
+        need = _meets(rays[finite].astype(np.float64), lo, hi)
+        have = sets[finite][:, ids]
+        missing = need & ~have
+        assert not missing.any(), (name, factor, density, np.argwhere(missing)[:5], info)
+        total += int(need.sum())
+        if name == "far_and_bad":
+            assert info["unwalked"] >= 5                  # the non-finite rays and the zero direction... and whatever lies beyond the reach
+    assert total > 20000
+
+
+def test_grid_of_the_bench_scene_is_small_and_cheap(pt):
+    """configs[3]: the figures DESIGN.md quotes -- the walls are the big primitives, the grid fits beside the tables in LDS,
+    a ray tests about a third of the bounds the two-level clusters made it test (28.6)."""
+    sc = orc.load_golden_scene("random256")
+    geoms, _, _ = to_product(sc)
+    lo, hi, ids = _boxes(sc.geoms)
+    rng = np.random.default_rng(1)
+    rays = _ray_families(lo, hi, rng, 20000)["interior"]
+    sets, info = pt.grid_probe(geoms, rays, 0)
+    assert info["big"] == 5 and info["unwalked"] == 0
+    assert info["cells"] <= 2048 and info["lds_bytes"] <= 10 * 1024
+    assert sets.sum(1).mean() < 12.0
+    assert info["mean_walk"] <= 9
+
+
+def test_grid_when_everything_is_big_or_flat(pt):
+    """Degenerate scenes still give a valid index: co-located primitives (one crowded cell), a flat sheet of primitives
+    (a one-cell-thick grid), and a scene whose primitives all span it (all of them big: an empty grid)."""
+    base = orc.load_golden_scene("random256")
+    rng = np.random.default_rng(7)
+    xf, inv = np.zeros(16, np.float32), np.zeros(16, np.float32)
+
+    def make(transforms):
+        geoms = []
+        for i, (t, r, s) in enumerate(transforms):
+            orc.lib().orc_build_transform(orc.vec3(*t), orc.vec3(*r), orc.vec3(*s), orc.fptr(xf), orc.fptr(inv))
+            g = orc.Geom()
+            g.type, g.materialid = i & 1, 0
+            for k in range(16):
+                g.transform[k] = float(xf[k]); g.inverseTransform[k] = float(inv[k])
+            geoms.append(g)
+        return orc.Scene(geoms, base.materials, base.camera)
+
+    scenes = {
+        "colocated": make([((1.0, 2.0, 3.0), (10.0 * i, 0, 0), (0.5, 0.5, 0.5)) for i in range(40)]),
+        "sheet": make([((float(i % 10), 0.0, float(i // 10)), (0, 0, 0), (0.6, 0.6, 0.6)) for i in range(100)]),
+        "all_big": make([((0.1 * i, 0.0, 0.0), (0, 0, 7.0 * i), (8.0, 8.0, 8.0)) for i in range(40)]),
+    }
+    for name, sc in scenes.items():
+        geoms, _, _ = to_product(sc)
+        lo, hi, ids = _boxes(sc.geoms)
+        for fam, rays in _ray_families(lo, hi, rng, 2000).items():
+            sets, info = pt.grid_probe(geoms, rays, 0)
+            assert info["duplicates"] == 0, (name, fam, info)
+            finite = np.isfinite(rays).all(1)
+            need = _meets(rays[finite].astype(np.float64), lo, hi)
+            assert not (need & ~sets[finite][:, ids]).any(), (name, fam, info)

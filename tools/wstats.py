@@ -1,5 +1,6 @@
-"""Stage statistics of the whole-path kernel for 33..256 primitives (k_path_w): groups per stage and their lane fill.
-Needs a -DPT_CULL_STATS build:  tools/build_variant.sh stats -DPT_CULL_STATS ;  PTMI355_LIB=.../build/variants/stats.so python3 tools/wstats.py [scene] [key=value ...]"""
+"""Stage statistics of the whole-path kernel for 33..256 primitives (k_path_w): groups per stage, their lane fill, and the
+phase clock.  Needs a -DPT_CULL_STATS build:  tools/build_variant.sh stats -DPT_CULL_STATS ;
+PTMI355_LIB=.../build/variants/stats.so python3 tools/wstats.py [scene] [key=value ...]"""
 import ctypes as C, importlib, os, sys
 sys.path.insert(0, os.getcwd())
 pkg = importlib.import_module("project2-pathtracer_amd")
@@ -9,13 +10,20 @@ sf = pkg.SceneFile(args[0] if args else "scenes/random256.txt"); g, m, cam = sf.
 tr = pkg.PathTracer(pkg.default_config(max_depth=8, ordering=2, **kw)); tr.upload(g, m, cam); tr.set_image(None)
 tr.render(1, 4); tr.sync()
 st = tr.stats()
-out = (C.c_ulonglong * 16)(); pkg.lib().pt_debug_cull_stats(out)
+out = (C.c_ulonglong * 32)(); pkg.lib().pt_debug_wide_stats(out)
 s = [int(v) for v in out]
 live = sum(int(st.live[k]) for k in range(8))
 per = live / 64.0
+d = lambda a, b: a / max(b, 1)
 print("live ray-bounces", live, "= %.0f groups of 64" % per)
-print("FRESH groups per 64 ray-bounces %.3f at %.1f lanes" % (s[0] / per, s[1] / max(s[0], 1)))
-print("PAIR chunks per 64 ray-bounces %.3f at %.1f lanes; member tests per ray %.2f; member-loop trips per chunk (max over lanes) %.2f" % (s[2] / per, s[3] / max(s[2], 1), s[13] / max(live, 1), s[15] / max(s[2], 1)))
-print("candidates per ray %.2f; overflow rays %d" % (s[10] / max(live, 1), s[11]))
-print("TEST cube groups per 64 ray-bounces %.3f at %.1f lanes; sphere groups %.3f at %.1f lanes; exact tests per ray %.2f" % (s[4] / per, s[5] / max(s[4], 1), s[6] / per, s[7] / max(s[6], 1), (s[5] + s[7]) / max(live, 1)))
-print("done lanes per TEST group %.1f, shaded %.1f; requeued %.1f (of them after a win %.1f)" % (s[9] / max(s[4] + s[6], 1), s[8] / max(s[4] + s[6], 1), s[12] / max(s[4] + s[6], 1), s[14] / max(s[4] + s[6], 1)))
+print("FRESH groups per 64 ray-bounces %.3f at %.1f lanes; bound tests of big primitives per ray %.2f; rays not walked %d" % (s[0] / per, d(s[1], s[0]), d(s[25], live), s[24]))
+print("WALK trips per FRESH group %.2f at %.1f lanes (cells per ray %.2f); non-empty cells per ray %.2f" % (d(s[2], s[0]), d(s[3], s[2]), d(s[3], live), d(s[4], live)))
+print("CELLS chunks per 64 ray-bounces %.3f at %.1f lanes (references read per ray %.2f); new ones per ray %.2f" % (s[5] / per, d(s[6], s[5]), d(s[6], live), d(s[9], live)))
+print("BOUNDS cube chunks per 64 ray-bounces %.3f at %.1f lanes; sphere chunks %.3f at %.1f lanes" % (s[10] / per, d(s[11], s[10]), s[12] / per, d(s[13], s[12])))
+print("candidates per ray %.2f; overflowed or unwalked rays %d" % (d(s[14] , live) + 0.0, s[15]))
+print("TEST cube groups per 64 ray-bounces %.3f at %.1f lanes; sphere groups %.3f at %.1f lanes; exact tests per ray %.2f" % (s[16] / per, d(s[17], s[16]), s[18] / per, d(s[19], s[18]), d(s[17] + s[19], live)))
+print("done lanes per TEST group %.1f, shaded %.1f; requeued %.1f (of them after a win %.1f)" % (d(s[21], s[16] + s[18]), d(s[20], s[16] + s[18]), d(s[22], s[16] + s[18]), d(s[23], s[16] + s[18])))
+ph = (C.c_ulonglong * 16)(); pkg.lib().pt_debug_phase_cycles(ph)
+ph = [int(v) for v in ph][:10]; tot = float(sum(ph)) or 1.0
+names = ["schedule", "fresh load + big primitives", "walk", "cells", "bounds", "select", "test load + exact test", "next candidate", "shading", "requeue + survivors"]
+print("phase clock (share of the waves' cycles): " + ", ".join("%s %.1f%%" % (n, 100.0 * v / tot) for n, v in zip(names, ph)))
