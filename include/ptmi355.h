@@ -252,9 +252,11 @@ int  pt_debug_light_points(pt_context *ctx, int geom, int n, const float *seeds,
 /* The spatial index of the whole-path kernel for 33..256 primitives, probed WITHOUT a device: builds the uniform grid of
  * the scene as pt_upload_scene does and walks nrays rays (6 floats each: origin, direction) on the host with the kernel's
  * own walk functions.  out_sets: nrays x 8 words, bit p of a ray = primitive p gets its bound tested for that ray (every
- * bit for a ray the kernel would not walk: it takes the reference loop).  out_info[16]: [0] cells [1] references [2] big
+ * bit for a ray the kernel would not walk: it takes the reference loop).  out_info: [0] cells [1] references [2] big
  * primitives [3] primitives listed twice for a ray (must be 0) [4] rays not walked [5..7] cells per axis [8] mean and
- * [9] longest walk in cells [10] non-empty cells and [11] listed primitives per ray x 100 [12] bytes of LDS. */
+ * [9] longest walk in cells [10] non-empty cells and [11] listed primitives per ray x 100 [12] bytes of LDS [13] [14] the walk
+ * lengths that separate the three bins survivors are sorted into [15] worst and [16] mean x 100 error of the length estimate
+ * behind that sorting (cells).  out_info holds 24 words. */
 int  pt_debug_grid_probe(const pt_geom *geoms, int ngeoms, int density, const float *rays, int nrays,
                          uint32_t *out_sets, uint32_t *out_info);
 

@@ -109,7 +109,8 @@ def lib():
     L.pt_debug_hemisphere.argtypes = [vp, C.c_int, fp, fp, fp]
     L.pt_debug_sincos.argtypes = [vp, C.c_int, fp, fp, fp]
     L.pt_debug_light_points.argtypes = [vp, C.c_int, C.c_int, fp, fp]
-    L.pt_debug_grid_probe.argtypes = [C.POINTER(Geom), C.c_int, C.c_int, fp, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    if hasattr(L, "pt_debug_grid_probe"):      # (absent from builds of older commits that tools/ab_lib.sh compares against)
+        L.pt_debug_grid_probe.argtypes = [C.POINTER(Geom), C.c_int, C.c_int, fp, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.pt_scene_load.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.pt_scene_free.argtypes = [vp]; L.pt_scene_free.restype = None
     L.pt_scene_counts.argtypes = [vp, ip, ip, ip, ip]
@@ -341,12 +342,12 @@ def grid_probe(geoms, rays, density=0):
     rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
     n = rays.shape[0]
     words = np.zeros((n, 8), dtype=np.uint32)
-    info = np.zeros(16, dtype=np.uint32)
+    info = np.zeros(24, dtype=np.uint32)
     _check(lib().pt_debug_grid_probe(geoms, len(geoms), int(density), _fp(rays), n,
                                      words.ctypes.data_as(C.POINTER(C.c_uint32)), info.ctypes.data_as(C.POINTER(C.c_uint32))))
     sets = np.unpackbits(words.view(np.uint8), axis=1, bitorder="little").astype(bool)
     names = ["cells", "refs", "big", "duplicates", "unwalked", "nx", "ny", "nz", "mean_walk", "longest_walk",
-             "cells_per_ray_x100", "listed_per_ray_x100", "lds_bytes"]
+             "cells_per_ray_x100", "listed_per_ray_x100", "lds_bytes", "bin1", "bin2", "length_estimate_worst", "length_estimate_mean_error_x100"]
     return sets, {k: int(v) for k, v in zip(names, info)}
 
 

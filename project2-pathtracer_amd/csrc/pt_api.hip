@@ -236,7 +236,7 @@ void world_bounds(const pt_geom &src, GeomRec *dst) {
 // farther or non-finite rays are not walked at all (the kernel gives them the reference loop).
 struct GridBuild { GridArgs ga; std::vector<unsigned char> blob; };
 
-void build_grid(const std::vector<GeomRec> &g, int G, int density, GridBuild *out) {
+void build_grid(const std::vector<GeomRec> &g, int G, int density, size_t max_bytes, GridBuild *out) {
     struct Box { double lo[3], hi[3]; int id; bool sphere; };
     std::vector<Box> prims;
     double maxabs = 0.0;
@@ -255,7 +255,7 @@ void build_grid(const std::vector<GeomRec> &g, int G, int density, GridBuild *ou
     memset(&ga, 0, sizeof ga);
     std::vector<char> big(prims.size(), 0);
     std::vector<std::vector<uint16_t>> lists;
-    double dens = density > 0 ? (double)density : 4.0;
+    double dens = density > 0 ? (double)density : density < 0 ? 0.125 : 4.0;
     int n[3] = {1, 1, 1};
     double gmin[3] = {0, 0, 0}, h[3] = {1, 1, 1};
     for (int attempt = 0; attempt < 12; ++attempt) {
@@ -336,6 +336,11 @@ void build_grid(const std::vector<GeomRec> &g, int G, int density, GridBuild *ou
     const size_t nrefs = refs.size(), nrefs_even = (nrefs + 1) & ~(size_t)1;
     size_t bytes = (size_t)ncells * 4 + nrefs_even * 2 + bigs.size();
     bytes = (bytes + 15) & ~(size_t)15;
+    if ((bytes > max_bytes || nrefs > 8191) && ncells > 1) {             // no room beside the tables in LDS (or beyond the 13-bit reference index): coarser
+        const int next = (int)std::floor(dens * 0.7);
+        if (next >= 1 && density != 1) { build_grid(g, G, next, max_bytes, out); return; }
+        if (density != -1) { build_grid(g, G, -1, max_bytes, out); return; }           // -1: one cell per 8 primitives, the coarsest the builder makes
+    }
     out->blob.assign(bytes, 0);
     memcpy(out->blob.data(), cellrec.data(), (size_t)ncells * 4);
     if (nrefs) memcpy(out->blob.data() + (size_t)ncells * 4, refs.data(), nrefs * 2);
@@ -347,6 +352,11 @@ void build_grid(const std::vector<GeomRec> &g, int G, int density, GridBuild *ou
         diag2 += (h[k] * n[k]) * (h[k] * n[k]);
     }
     ga.reach = (float)(8.0 * std::sqrt(diag2));
+    {   // the survivors' bins by walk length: short <= ~0.45 x the mean cell count per axis, middle <= twice that
+        const double navg = (n[0] + n[1] + n[2]) / 3.0;
+        const uint32_t b1 = (uint32_t)std::max(2.0, std::floor(0.45 * navg + 0.5));
+        ga.bin1 = b1; ga.bin2 = 2u * b1;
+    }
     ga.ncells = ncells; ga.nrefs = (uint32_t)nrefs; ga.nbig = (uint32_t)bigs.size();
     ga.blob_bytes = (uint32_t)bytes;
     ga.blob = nullptr;
@@ -1021,7 +1031,9 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         // ordering = 2 with 33..256 analytic primitives: k_path_w -- one big block per CU shares the geometry table; per-wave
         // ray slots and work stacks in LDS, the survivors' stacks and the slots' payload in one arena per wave
         GridBuild gb;
-        build_grid(g, G, c->cfg.grid_density, &gb);
+        // (the smallest block shape of k_path_w leaves 160 KB - tables - 89 KB to the grid)
+        const size_t grid_room = 160u * 1024u - tables_bytes(G, M, true) - 91136u;
+        build_grid(g, G, c->cfg.grid_density, grid_room < 24u * 1024u ? grid_room : 24u * 1024u, &gb);
         c->grid = gb.ga;
         HIPCHK(hipMalloc(&c->d_grid, gb.blob.size()));
         HIPCHK(hipMemcpy(c->d_grid, gb.blob.data(), gb.blob.size(), hipMemcpyHostToDevice));
@@ -1031,7 +1043,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         {
             // the block shape asked for, or the next one that leaves room for the grid beside the tables
             hipError_t e = wide_setup(c->wide_variant, G, M, c->grid.blob_bytes, &wl);
-            for (int v = 0; e == hipErrorInvalidValue && v < 3; ++v) { c->wide_variant = v; e = wide_setup(v, G, M, c->grid.blob_bytes, &wl); }
+            for (int v = 3; e == hipErrorInvalidValue && v >= 1; --v) { c->wide_variant = v; e = wide_setup(v, G, M, c->grid.blob_bytes, &wl); }
             HIPCHK(e);
         }
         c->lds_path = wl.lds_bytes;
@@ -1052,7 +1064,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
             c->wide_qscale = (float)(250.0 / (diag > 0.0 ? diag : 1.0));
             c->wide_slack = (float)smax;
         }
-        c->arena_bytes = (size_t)c->grid_path * wl.waves_per_block * ((size_t)kSFields * wl.stack_slots + (size_t)kWPayload * wl.slots_per_wave) * sizeof(float);
+        c->arena_bytes = (size_t)c->grid_path * wl.waves_per_block * ((size_t)kWalkBins * kSFields * wl.stack_slots + (size_t)kWPayload * wl.payload_per_wave) * sizeof(float);
         if (c->arena_bytes >= (1ull << 32)) { pth::set_error("pt_upload_scene: k_path_w arena of %zu bytes exceeds buffer addressing", c->arena_bytes); return PT_ERR_ARGUMENT; }
         HIPCHK(hipMalloc(&c->d_arena, c->arena_bytes));
         HIPCHK(hipMalloc(&c->d_tickets, (size_t)kTicketCtrs * kTicketStride * sizeof(uint32_t)));
@@ -1234,12 +1246,13 @@ int pt_debug_grid_probe(const pt_geom *geoms, int G, int density, const float *r
     std::vector<GeomRec> g(G);
     for (int i = 0; i < G; ++i) { memset(&g[i], 0, sizeof(GeomRec)); g[i].type = geoms[i].type; world_bounds(geoms[i], &g[i]); }
     GridBuild gb;
-    build_grid(g, G, density, &gb);
+    build_grid(g, G, density, 24u * 1024u, &gb);
     const GridArgs &ga = gb.ga;
     const uint32_t *cells = reinterpret_cast<const uint32_t *>(gb.blob.data());
     const uint16_t *refs = reinterpret_cast<const uint16_t *>(cells + ga.ncells);
     const unsigned char *bigs = reinterpret_cast<const unsigned char *>(refs + ((ga.nrefs + 1u) & ~1u));
-    uint32_t dups = 0, unwalked = 0, maxtrips = 0;
+    uint32_t dups = 0, unwalked = 0, maxtrips = 0, est_worst = 0;
+    uint64_t est_abs = 0;
     uint64_t trips_total = 0, entries = 0, news = 0;
     for (int r = 0; r < nrays; ++r) {
         uint32_t *set = out_sets + (size_t)r * 8;
@@ -1271,6 +1284,12 @@ int pt_debug_grid_probe(const pt_geom *geoms, int G, int density, const float *r
             grid_walk_step(w);
         }
         if (w.walking) dups += 1000000u;                                   // the step bound must never cut a walk short
+        {   // the length estimate the survivors are sorted by: never short of the walk by more than the ties can explain
+            const uint32_t est = grid_walk_length(ga, o, d, inv);
+            const uint32_t err = est > trips ? est - trips : trips - est;
+            if (err > est_worst) est_worst = err;
+            est_abs += err;
+        }
         trips_total += trips;
         if (trips > maxtrips) maxtrips = trips;
     }
@@ -1278,7 +1297,8 @@ int pt_debug_grid_probe(const pt_geom *geoms, int G, int density, const float *r
     out_info[5] = (uint32_t)ga.n[0]; out_info[6] = (uint32_t)ga.n[1]; out_info[7] = (uint32_t)ga.n[2];
     out_info[8] = (uint32_t)(nrays ? trips_total / (uint64_t)nrays : 0); out_info[9] = maxtrips;
     out_info[10] = (uint32_t)(nrays ? (100 * entries) / (uint64_t)nrays : 0); out_info[11] = (uint32_t)(nrays ? (100 * news) / (uint64_t)nrays : 0);
-    out_info[12] = ga.blob_bytes;
+    out_info[12] = ga.blob_bytes; out_info[13] = ga.bin1; out_info[14] = ga.bin2;
+    out_info[15] = est_worst; out_info[16] = (uint32_t)(nrays ? (100 * est_abs) / (uint64_t)nrays : 0);
     return PT_OK;
 }
 

@@ -82,6 +82,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_path_q(SegArgs a, PathArgs pa, co
 
     for (;;) {
         if (++turns > pa.turn_limit) { if (lane == 0) *pa.error = 3u; break; }                // never reached; bounds a broken build
+        // the scheduler's state is wave-uniform by construction; saying so keeps its arithmetic and its branches on the scalar unit
+        nbox = __builtin_amdgcn_readfirstlane(nbox); nsph = __builtin_amdgcn_readfirstlane(nsph); sp = __builtin_amdgcn_readfirstlane(sp);
+        jobpos = __builtin_amdgcn_readfirstlane(jobpos); jobend = __builtin_amdgcn_readfirstlane(jobend);
+        round = __builtin_amdgcn_readfirstlane(round); ctr = __builtin_amdgcn_readfirstlane(ctr); dry = __builtin_amdgcn_readfirstlane(dry);
         int act;
         if (nbox >= 64u) act = 1;
         else if (nsph >= 64u) act = 2;

@@ -53,7 +53,8 @@ static __device__ unsigned long long g_wstats[32];
 // [0] FRESH groups [1] valid lanes [2] walk trips [3] walking lanes [4] (ray, cell) entries [5] CELLS chunks [6] lanes [7] -
 // [8] - [9] (ray, primitive) entries [10] BOUNDS cube chunks [11] lanes [12] BOUNDS sphere chunks [13] lanes [14] candidates
 // [15] overflowed / unwalked rays [16] TEST cube groups [17] lanes [18] TEST sphere groups [19] lanes [20] shaded [21] done
-// [22] requeued [23] requeued after a win [24] unwalked rays [25] bound tests of big primitives (lanes)
+// [22] requeued [23] requeued after a win [24] unwalked rays [25] bound tests of big primitives (lanes) [26] SHADE cube-hit groups [27] lanes
+// [28] SHADE sphere-hit groups [29] lanes
 __device__ __forceinline__ void wstat(int i, unsigned long long v) { if ((threadIdx.x & 63) == 0 && v) atomicAdd(&g_wstats[i], v); }
 #define PT_WSTAT(i, v) wstat((i), (unsigned long long)(v))
 #else
@@ -65,11 +66,12 @@ namespace {
 // slot fields (SoA, stride R dwords, wave-private LDS)
 enum : uint32_t { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_L0, F_L1, F_L2, F_L3, F_META, F_BEST, F_COUNT };
 // payload fields (SoA, stride R floats, global memory, per wave)
-enum : uint32_t { P_TX = 0, P_TY, P_TZ, P_PV, P_LEVEL, P_PX, P_PY, P_PZ, P_NX, P_NY, P_NZ };
-static_assert(P_NZ + 1 == kWPayload, "payload record");
+enum : uint32_t { P_TX = 0, P_TY, P_TZ, P_PV, P_LEVEL, P_PX, P_PY, P_PZ, P_NX, P_NY, P_NZ, P_DX, P_DY, P_DZ, P_HIT };
+static_assert(P_HIT + 1 == kWPayload, "payload record");
+static_assert(kWalkBins == 3, "the survivors' stacks are written out as sp0, sp1, sp2");
 static_assert(100 * 4 + sizeof(GridArgs) <= kCtrlBytes, "the parked GridArgs must fit behind the survivors' counters in the control block");
 
-constexpr uint32_t kMetaHasHit = 1u << 27;
+constexpr uint32_t kMetaHasHit = 1u << 27;      // slot word while a ray waits for a TEST: candidate | best hit << 8 | (face + 1) << 16 | payload id << 19 | this bit
 constexpr uint32_t kListCap = 8;
 constexpr uint32_t kBufA = 128;        // (ray, cell) entries: a walk trip adds <= 64 to <= 63 waiting
 constexpr uint32_t kBufC = 192;        // (ray, primitive) entries, cubes from the bottom, spheres from the top: a CELLS trip adds <= 64 to <= 63 + 63
@@ -98,10 +100,14 @@ __device__ __forceinline__ uint32_t select_next(const uint32_t L[4], uint32_t qm
 
 }  // namespace
 
-template <int WAVES, int R>
+template <int WAVES, int R, int NP>
 __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, GridArgs ga, const GeomRec *__restrict__ geoms,
                                                         const MatRec *__restrict__ mats, const FaceFrame *__restrict__ frames) {
-    constexpr uint32_t STK = (uint32_t)((R + 64 + 63) / 64 * 64);      // survivors' stack: at most 63 + R rays wait for their next bounce
+    static_assert(R % 4 == 0 && NP % 4 == 0 && R <= 256 && NP <= 256 && NP >= R + 64, "slot and payload ids are bytes");
+    // survivors wait for their next bounce on kWalkBins stacks, sorted by the length of the walk ahead of them, so that the rays of
+    // a FRESH group walk about equally far.  New (camera) rays only enter while no stack holds a full wave and 64 payload records
+    // are free, so the wave never holds more than NP + 63 * kWalkBins rays in all: no stack outgrows STK
+    constexpr uint32_t STK = (uint32_t)((NP + 64 * kWalkBins + 63) / 64 * 64);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *ctrl = reinterpret_cast<uint32_t *>(smem);   // [1] emitted (block sum), [18..31] parked constants, [32..96] survivors per level
     uint32_t *lsurv = ctrl + 32;
@@ -134,22 +140,26 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
     const uint32_t wslot = blockIdx.x * WAVES + wave;
     const uint32_t nwaves = gridDim.x * WAVES;
     const uint32_t D = pa.depth;
-    // the wave's LDS region: 12 slot fields x R | typed stacks of slot ids (cubes up, spheres down) | free list | the two pair buffers
-    uint32_t *wl = reinterpret_cast<uint32_t *>(smem + tb + ga.blob_bytes) + (size_t)wave * (14u * R + kBufA + kBufC);
+    // the wave's LDS region: 12 slot fields x R | byte lists: typed stacks of slot ids waiting for a TEST (cubes up, spheres down),
+    // free slots, free payload records, typed stacks of payload ids waiting for SHADE (cube hits up, sphere hits down) | the two pair buffers
+    constexpr uint32_t kListDwords = (2u * R + 2u * NP) / 4u;
+    uint32_t *wl = reinterpret_cast<uint32_t *>(smem + tb + ga.blob_bytes) + (size_t)wave * (12u * R + kListDwords + kBufA + kBufC);
     float *wf = reinterpret_cast<float *>(wl);
-    uint32_t *xstack = wl + 12u * R, *freel = wl + 13u * R, *bufA = wl + 14u * R, *bufC = bufA + kBufA;
-    for (uint32_t i = lane; i < (uint32_t)R; i += 64u) freel[i] = i;
-    uint32_t nfree = R;
+    unsigned char *xstack = reinterpret_cast<unsigned char *>(wl + 12u * R), *freel = xstack + R, *pfree = freel + R, *shstack = pfree + NP;
+    uint32_t *bufA = wl + 12u * R + kListDwords, *bufC = bufA + kBufA;
+    for (uint32_t i = lane; i < (uint32_t)R; i += 64u) freel[i] = (unsigned char)i;
+    for (uint32_t i = lane; i < (uint32_t)NP; i += 64u) pfree[i] = (unsigned char)i;
+    uint32_t nfree = R, npfree = NP;
 
-    // the wave's arena in global memory: the survivors' stack (kSFields x STK) and the slots' payload (kWPayload x R)
-    const uint32_t wave_floats = kSFields * STK + kWPayload * (uint32_t)R;
+    // the wave's arena in global memory: the survivors' stacks (kWalkBins x kSFields x STK) and the payload records (kWPayload x NP)
+    const uint32_t wave_floats = kWalkBins * kSFields * STK + kWPayload * (uint32_t)NP;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pa.arena, 0, pa.arena_bytes, 0x00020000);
     const uint32_t woff = wslot * wave_floats;             // in floats; the arena is below 4 GiB (checked by the host)
-    const uint32_t poff = woff + kSFields * STK;
+    const uint32_t poff = woff + kWalkBins * kSFields * STK;
     auto ring_ld = [&](uint32_t off, uint32_t f) -> float { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off * 4u, f * STK * 4u, 0)); };
     auto ring_st = [&](uint32_t off, uint32_t f, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, off * 4u, f * STK * 4u, 0); };
-    auto pay_ld = [&](uint32_t sid, uint32_t f) -> float { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (poff + sid) * 4u, f * (uint32_t)R * 4u, 0)); };
-    auto pay_st = [&](uint32_t sid, uint32_t f, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, (poff + sid) * 4u, f * (uint32_t)R * 4u, 0); };
+    auto pay_ld = [&](uint32_t pid, uint32_t f) -> float { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (poff + pid) * 4u, f * (uint32_t)NP * 4u, 0)); };
+    auto pay_st = [&](uint32_t pid, uint32_t f, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, (poff + pid) * 4u, f * (uint32_t)NP * 4u, 0); };
 
     uint32_t *bank = a.bank ? a.sync->counts_b : a.sync->counts;
     if (blockIdx.x == 0 && threadIdx.x < 72) {
@@ -161,7 +171,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
 
     uint32_t emitted = 0u;
     uint32_t nbox = 0u, nsph = 0u;                         // slots waiting on the two typed stacks
-    uint32_t sp = 0u;                                      // rays on the wave's stack of survivors
+    uint32_t nshb = 0u, nshs = 0u;                         // payload records waiting to be shaded: cube hits, sphere hits
+    uint32_t sp0 = 0u, sp1 = 0u, sp2 = 0u;                 // rays on the wave's stacks of survivors: short, middle and long walks ahead
     uint32_t jobpos = 0u, jobend = 0u;
     bool tickets_left = true;
     uint32_t next_ticket = 0u, round = 0u;
@@ -196,15 +207,27 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
         PT_PHASE(0);
         // the scheduler's state is wave-uniform by construction; saying so keeps its arithmetic on the scalar unit
         nbox = __builtin_amdgcn_readfirstlane(nbox); nsph = __builtin_amdgcn_readfirstlane(nsph); nfree = __builtin_amdgcn_readfirstlane(nfree);
-        sp = __builtin_amdgcn_readfirstlane(sp); jobpos = __builtin_amdgcn_readfirstlane(jobpos); jobend = __builtin_amdgcn_readfirstlane(jobend);
+        nshb = __builtin_amdgcn_readfirstlane(nshb); nshs = __builtin_amdgcn_readfirstlane(nshs); npfree = __builtin_amdgcn_readfirstlane(npfree);
+        sp0 = __builtin_amdgcn_readfirstlane(sp0); sp1 = __builtin_amdgcn_readfirstlane(sp1); sp2 = __builtin_amdgcn_readfirstlane(sp2);
+        jobpos = __builtin_amdgcn_readfirstlane(jobpos); jobend = __builtin_amdgcn_readfirstlane(jobend);
         round = __builtin_amdgcn_readfirstlane(round); ctr = __builtin_amdgcn_readfirstlane(ctr); dry = __builtin_amdgcn_readfirstlane(dry);
         turns = __builtin_amdgcn_readfirstlane(turns);
         if (++turns > pa.turn_limit) { if (lane == 0) *pa.error = 3u; break; }             // never reached; bounds a broken build
-        int act;                                                                           // 0 FRESH from the stack, 3 FRESH camera rays, 1 TEST cubes, 2 TEST spheres
-        if (nbox >= 64u) act = 1;
+        int act;                                           // 0 FRESH from the stack, 3 FRESH camera rays, 1 TEST cubes, 2 TEST spheres, 4 SHADE cube hits, 5 SHADE sphere hits
+        // whatever holds a full wave runs; else a fresh group while slots and payload records are free; else the fullest stage
+        auto fullest = [&]() -> int {
+            uint32_t m = nbox; int w = 1;
+            if (nsph > m) { m = nsph; w = 2; }
+            if (nshb > m) { m = nshb; w = 4; }
+            if (nshs > m) { m = nshs; w = 5; }
+            return m ? w : -1;
+        };
+        if (nshb >= 64u) act = 4;
+        else if (nshs >= 64u) act = 5;
+        else if (nbox >= 64u) act = 1;
         else if (nsph >= 64u) act = 2;
-        else if (nfree >= 64u) {
-            if (sp >= 64u) act = 0;
+        else if (nfree >= 64u && npfree >= 64u) {
+            if (sp0 >= 64u || sp1 >= 64u || sp2 >= 64u) act = 0;
             else {
                 while (jobpos >= jobend && tickets_left) {                                 // next job of camera rays (a dry counter: try the next)
                     unsigned long long job;
@@ -225,11 +248,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
                     if (first < (unsigned long long)a.n_rays) { jobpos = (uint32_t)first; jobend = a.n_rays - jobpos < pa.job_rays ? a.n_rays : jobpos + pa.job_rays; }
                 }
                 if (jobpos < jobend) act = 3;
-                else if (sp) act = 0;
-                else if (nbox + nsph) act = nbox >= nsph ? 1 : 2;
-                else break;
+                else if (sp0 | sp1 | sp2) act = 0;
+                else { act = fullest(); if (act < 0) break; }
             }
-        } else act = nbox >= nsph ? 1 : 2;                                                 // no room for a fresh group: the fuller stack pops what it has
+        } else { act = fullest(); if (act < 0) { if (lane == 0) *pa.error = 2u; break; } }  // (never: without room for a fresh group something waits)
 
         if (act == 0 || act == 3) {
             // ================================================================ FRESH
@@ -250,11 +272,21 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
                     camera_ray(a.cam, pixel, a.iteration + slot, o, d);
                     pv = pixel | (slot << 24);
                 }
-            } else {                                                                       // the top of the wave's stack of survivors
-                const uint32_t cnt = sp < 64u ? sp : 64u;
-                valid = lane < cnt;
-                sp -= cnt;
-                const uint32_t off = woff + sp + lane;
+            } else {                                                                       // the top of a stack of survivors that holds a full wave;
+                // none does (the launch is draining: no camera rays left): the longest walks first, topped up from the shorter ones
+                uint32_t t2, t1, t0;
+                if (sp2 >= 64u) { t2 = 64u; t1 = 0u; t0 = 0u; }
+                else if (sp1 >= 64u) { t2 = 0u; t1 = 64u; t0 = 0u; }
+                else if (sp0 >= 64u) { t2 = 0u; t1 = 0u; t0 = 64u; }
+                else {
+                    t2 = sp2;
+                    t1 = sp1 < 64u - t2 ? sp1 : 64u - t2;
+                    t0 = sp0 < 64u - t2 - t1 ? sp0 : 64u - t2 - t1;
+                }
+                valid = lane < t2 + t1 + t0;
+                sp2 -= t2; sp1 -= t1; sp0 -= t0;
+                const uint32_t off = woff + (lane < t2 ? 2u * (kSFields * STK) + sp2 + lane
+                                             : lane < t2 + t1 ? 1u * (kSFields * STK) + sp1 + (lane - t2) : sp0 + (lane - t2 - t1));
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // the wave's own stack stores have landed (vmcnt 0) ...
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");        // ... before they are read back through the same L1
                 if (valid) {
@@ -269,16 +301,19 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
             // a slot for every ray of the group
             const u64 vb = __ballot(valid);
             const uint32_t nv = (uint32_t)__popcll(vb);
-            uint32_t sid = 0u;
+            uint32_t sid = 0u, pid = 0u;
             if (valid) {
                 sid = freel[nfree - 1u - wave_rank(vb)];
+                pid = pfree[npfree - 1u - wave_rank(vb)];
                 wf[F_OX * R + sid] = o.x; wf[F_OY * R + sid] = o.y; wf[F_OZ * R + sid] = o.z;
                 wf[F_DX * R + sid] = d.x; wf[F_DY * R + sid] = d.y; wf[F_DZ * R + sid] = d.z;
                 wl[F_L0 * R + sid] = 0xFFFFFFFFu; wl[F_L1 * R + sid] = 0xFFFFFFFFu; wl[F_L2 * R + sid] = 0xFFFFFFFFu; wl[F_L3 * R + sid] = 0xFFFFFFFFu;
-                pay_st(sid, P_TX, thr.x); pay_st(sid, P_TY, thr.y); pay_st(sid, P_TZ, thr.z);
-                pay_st(sid, P_PV, __uint_as_float(pv)); pay_st(sid, P_LEVEL, __uint_as_float(level));
+                // what only the shading needs waits in the ray's payload record: throughput, pixel word, level, direction
+                pay_st(pid, P_TX, thr.x); pay_st(pid, P_TY, thr.y); pay_st(pid, P_TZ, thr.z);
+                pay_st(pid, P_PV, __uint_as_float(pv)); pay_st(pid, P_LEVEL, __uint_as_float(level));
+                pay_st(pid, P_DX, d.x); pay_st(pid, P_DY, d.y); pay_st(pid, P_DZ, d.z);
             }
-            nfree -= nv;
+            nfree -= nv; npfree -= nv;
             const CullRay cr = make_cull_ray(o, d);
             // ---------------------------------------------------------------- the big primitives: every ray, wave-uniform index
             uint32_t ncand0 = 0u;
@@ -472,7 +507,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
                     wl[(F_L0 + (pos >> 1)) * R + sid] = L[pos >> 1] | clr;
                 }
                 if (queued) {
-                    wl[F_META * R + sid] = first_id;                                       // current candidate, no hit yet
+                    wl[F_META * R + sid] = first_id | (pid << 19);                         // current candidate, no hit yet
                     wf[F_BEST * R + sid] = kInf;
                     tobox = lg[first_id].type == 1;
                 }
@@ -481,164 +516,208 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
                 const u64 bb = __ballot(queued && tobox), sb = __ballot(queued && !tobox), fb = __ballot(valid && !queued);
                 if (queued) {
                     const uint32_t pos = tobox ? nbox + wave_rank(bb) : (uint32_t)R - 1u - (nsph + wave_rank(sb));
-                    xstack[pos] = sid;
+                    xstack[pos] = (unsigned char)sid;
                 }
-                if (valid && !queued) freel[nfree + wave_rank(fb)] = sid;                  // no candidate at all: the ray leaves the scene
+                if (valid && !queued) {                                                    // no candidate at all: the ray leaves the scene
+                    freel[nfree + wave_rank(fb)] = (unsigned char)sid;
+                    pfree[npfree + wave_rank(fb)] = (unsigned char)pid;
+                }
                 nbox += (uint32_t)__popcll(bb);
                 nsph += (uint32_t)__popcll(sb);
-                nfree += (uint32_t)__popcll(fb);
+                nfree += (uint32_t)__popcll(fb); npfree += (uint32_t)__popcll(fb);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
             continue;
         }
 
-        // ==================================================================== TEST (one type per group, any levels)
-        PT_PHASE(6);
-        const bool isb = act == 1;
-        const uint32_t have = isb ? nbox : nsph;
-        const uint32_t cnt = have < 64u ? have : 64u;
-        const bool valid = lane < cnt;
-        const uint32_t qpos = isb ? (have - cnt + lane) : ((uint32_t)R - 1u - (have - cnt + lane));
-        if (isb) nbox -= cnt; else nsph -= cnt;
-        PT_WSTAT(isb ? 16 : 18, 1); PT_WSTAT(isb ? 17 : 19, cnt);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                // payload stores of earlier groups have landed ...
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");                // ... before they are read back through the same L1
-        uint32_t sid = 0u, meta = 0u;
-        uint32_t L[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-        f3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(0, 0, 0);
-        float best = kInf;
-        uint32_t pv = 0u, level = 0u;
-        f3 P = mk(0, 0, 0), N = mk(0, 0, 0);                                  // hit point / normal of the best hit so far
-        if (valid) {
-            sid = xstack[qpos];
-            o = mk(wf[F_OX * R + sid], wf[F_OY * R + sid], wf[F_OZ * R + sid]);
-            d = mk(wf[F_DX * R + sid], wf[F_DY * R + sid], wf[F_DZ * R + sid]);
-            meta = wl[F_META * R + sid];
-            best = wf[F_BEST * R + sid];
-            L[0] = wl[F_L0 * R + sid]; L[1] = wl[F_L1 * R + sid]; L[2] = wl[F_L2 * R + sid]; L[3] = wl[F_L3 * R + sid];
-            // throughput, pixel word and level: requested now, used after the test
-            thr = mk(pay_ld(sid, P_TX), pay_ld(sid, P_TY), pay_ld(sid, P_TZ));
-            pv = __float_as_uint(pay_ld(sid, P_PV));
-            level = __float_as_uint(pay_ld(sid, P_LEVEL));
-            if (meta & kMetaHasHit) {                                         // an earlier test of this ray holds the best hit so far
-                P = mk(pay_ld(sid, P_PX), pay_ld(sid, P_PY), pay_ld(sid, P_PZ));
-                N = mk(pay_ld(sid, P_NX), pay_ld(sid, P_NY), pay_ld(sid, P_NZ));
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t j = meta & 0xFFu;
-        bool has_hit = (meta & kMetaHasHit) != 0u;
-        uint32_t hit = (meta >> 8) & 0xFFu;
-        int face = (int)((meta >> 16) & 7u) - 1;
-        bool won = false;
-        {
-            const GeomRec *gr = lg + j;                                       // per-lane gather from the LDS table
-            float depth = -1.0f;
-            f3 p = mk(0, 0, 0), n = mk(0, 0, 0);
-            int fc = -1;
+        if (act == 1 || act == 2) {
+            // ================================================================ TEST (one type per group, any levels)
+            PT_PHASE(6);
+            const bool isb = act == 1;
+            const uint32_t have = isb ? nbox : nsph;
+            const uint32_t cnt = have < 64u ? have : 64u;
+            const bool valid = lane < cnt;
+            const uint32_t qpos = isb ? (have - cnt + lane) : ((uint32_t)R - 1u - (have - cnt + lane));
+            if (isb) nbox -= cnt; else nsph -= cnt;
+            PT_WSTAT(isb ? 16 : 18, 1); PT_WSTAT(isb ? 17 : 19, cnt);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            uint32_t sid = 0u, meta = 0u;
+            uint32_t L[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            f3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+            float best = kInf;
             if (valid) {
-                if (isb) depth = box_test_face(gr->inv, gr->xf, gr->inside_hits, o, d, p, fc);
-                else depth = sphere_test(gr->inv, gr->xf, o, d, p, n);
+                sid = xstack[qpos];
+                o = mk(wf[F_OX * R + sid], wf[F_OY * R + sid], wf[F_OZ * R + sid]);
+                d = mk(wf[F_DX * R + sid], wf[F_DY * R + sid], wf[F_DZ * R + sid]);
+                meta = wl[F_META * R + sid];
+                best = wf[F_BEST * R + sid];
+                L[0] = wl[F_L0 * R + sid]; L[1] = wl[F_L1 * R + sid]; L[2] = wl[F_L2 * R + sid]; L[3] = wl[F_L3 * R + sid];
             }
-            // nearest-hit update of the reference loop: first strictly nearer wins, ties to the lower index
-            won = valid && depth > -PT_EPSILON && (has_hit ? (depth < best || (depth == best && j < hit)) : depth < kInf);
-            if (won) { best = depth; hit = j; P = p; N = n; face = fc; has_hit = true; }
-        }
-        // the next candidate that could still win or tie: key distance not beyond the best hit (conservative: one step of slack)
-        PT_PHASE(7);
-        uint32_t npos = 0u;
-        uint32_t qmax = 254u;
-        if (has_hit) {
-            const float lim = fminf((best + slack_max) * qscale, 253.0f);
-            qmax = (uint32_t)lim + 1u;
-        }
-        const uint32_t nkey = valid ? select_next(L, qmax, npos) : 0xFFFFu;
-        const bool more = nkey != 0xFFFFu;
-        const bool done = valid && !more;
-        bool nbx = false;
-        if (more) {
-            const uint32_t nid = nkey & 0xFFu;
-            const uint32_t clr = (npos & 1u) ? 0xFFFF0000u : 0x0000FFFFu;
-            wl[(F_L0 + (npos >> 1)) * R + sid] = L[npos >> 1] | clr;
-            wl[F_META * R + sid] = nid | (hit << 8) | ((uint32_t)(face + 1) << 16) | (has_hit ? kMetaHasHit : 0u);
-            wf[F_BEST * R + sid] = best;
-            if (won) {                                                        // the new best hit's point and normal wait in the payload record
-                pay_st(sid, P_PX, P.x); pay_st(sid, P_PY, P.y); pay_st(sid, P_PZ, P.z);
-                pay_st(sid, P_NX, N.x); pay_st(sid, P_NY, N.y); pay_st(sid, P_NZ, N.z);
-            }
-            nbx = lg[nid].type == 1;
-        }
-        PT_WSTAT(20, __popcll(__ballot(done && has_hit))); PT_WSTAT(21, __popcll(__ballot(done)));
-        PT_WSTAT(22, __popcll(__ballot(more))); PT_WSTAT(23, __popcll(__ballot(more && won)));
-        // ---------------------------------------------------------------- shade the finished rays that hit something
-        PT_PHASE(8);
-        bool alive = false;
-        if (done && has_hit) {
-            const uint32_t slot = a.batch > 1u ? pv >> 24 : 0u, pixel = pv & a.pix_mask;
-            const MatRec m = lm[lg[hit].mat];
-            if (level + 1u >= D && !(m.emittance > 0.0f)) {
-                alive = true;                                                 // depth exhausted: alive, contributes 0
-            } else {
-                const uint32_t iteration = a.iteration + slot;
-                uint32_t st = lcg_seed(stream_seed(pixel, iteration, 1u + level));
-                st = lcg_next(st); const float u_sel = u01(st);
-                st = lcg_next(st); const float xi1 = u01(st);
-                st = lcg_next(st); const float xi2 = u01(st);
-                f3 Lr = mk(0.0f, 0.0f, 0.0f);
-                int code = 4;
-                const bool hb = lg[hit].type == 1;
-                if (__any(hb)) { if (hb) code = scatter_box(m, P, face, frames + 3 * hit, u_sel, xi1, xi2, o, d, thr, Lr); }
-                if (__any(!hb)) { if (!hb) code = scatter(m, P, N, u_sel, xi1, xi2, o, d, thr, Lr); }
-                if (code == 3) {
-                    float *base = reinterpret_cast<float *>((uintptr_t)((unsigned long long)park[0] | ((unsigned long long)park[1] << 32)));
-                    size_t off = (size_t)pixel * 3;
-                    if (a.batch > 1u) {
-                        const uint32_t W = park[4];
-                        const uint32_t y = (uint32_t)(((unsigned long long)pixel * park[6]) >> park[7]);
-                        const uint32_t x = pixel - y * W;
-                        const uint32_t ly = (uint32_t)(((unsigned long long)(y - park[5]) * park[8]) >> park[9]);
-                        off = (size_t)slot * (size_t)((unsigned long long)park[2] | ((unsigned long long)park[3] << 32)) + (size_t)(ly * W + x) * 3;
-                    }
-                    float *px = base + off;
-                    (void)unsafeAtomicAdd(px, Lr.x); (void)unsafeAtomicAdd(px + 1, Lr.y); (void)unsafeAtomicAdd(px + 2, Lr.z);
-                    emitted++;
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t j = meta & 0xFFu, pid = (meta >> 19) & 0xFFu;
+            bool has_hit = (meta & kMetaHasHit) != 0u;
+            uint32_t hit = (meta >> 8) & 0xFFu;
+            int face = (int)((meta >> 16) & 7u) - 1;
+            bool won = false;
+            f3 P = mk(0, 0, 0), N = mk(0, 0, 0);
+            {
+                const GeomRec *gr = lg + j;                                   // per-lane gather from the LDS table
+                float depth = -1.0f;
+                int fc = -1;
+                if (valid) {
+                    if (isb) depth = box_test_face(gr->inv, gr->xf, gr->inside_hits, o, d, P, fc);
+                    else depth = sphere_test(gr->inv, gr->xf, o, d, P, N);
                 }
-                alive = code <= 2;
+                // nearest-hit update of the reference loop: first strictly nearer wins, ties to the lower index
+                won = valid && depth > -PT_EPSILON && (has_hit ? (depth < best || (depth == best && j < hit)) : depth < kInf);
+                if (won) { best = depth; hit = j; face = fc; has_hit = true; }
             }
-        }
-        if (alive) atomicAdd(&lsurv[level + 1u], 1u);
-        // ---------------------------------------------------------------- requeue / free / survivors
-        PT_PHASE(9);
-        {
-            const u64 bb = __ballot(more && nbx), sb = __ballot(more && !nbx), fb = __ballot(done);
+            // the new best hit's point and normal wait in the payload record (an earlier winner's stay there otherwise)
+            if (won) {
+                pay_st(pid, P_PX, P.x); pay_st(pid, P_PY, P.y); pay_st(pid, P_PZ, P.z);
+                if (!isb) { pay_st(pid, P_NX, N.x); pay_st(pid, P_NY, N.y); pay_st(pid, P_NZ, N.z); }
+            }
+            // the next candidate that could still win or tie: key distance not beyond the best hit (conservative: one step of slack)
+            PT_PHASE(7);
+            uint32_t npos = 0u;
+            uint32_t qmax = 254u;
+            if (has_hit) {
+                const float lim = fminf((best + slack_max) * qscale, 253.0f);
+                qmax = (uint32_t)lim + 1u;
+            }
+            const uint32_t nkey = valid ? select_next(L, qmax, npos) : 0xFFFFu;
+            const bool more = nkey != 0xFFFFu;
+            const bool done = valid && !more;
+            bool nbx = false;
             if (more) {
-                const uint32_t pos = nbx ? nbox + wave_rank(bb) : (uint32_t)R - 1u - (nsph + wave_rank(sb));
-                xstack[pos] = sid;
+                const uint32_t nid = nkey & 0xFFu;
+                const uint32_t clr = (npos & 1u) ? 0xFFFF0000u : 0x0000FFFFu;
+                wl[(F_L0 + (npos >> 1)) * R + sid] = L[npos >> 1] | clr;
+                wl[F_META * R + sid] = nid | (hit << 8) | ((uint32_t)(face + 1) << 16) | (pid << 19) | (has_hit ? kMetaHasHit : 0u);
+                wf[F_BEST * R + sid] = best;
+                nbx = lg[nid].type == 1;
             }
-            if (done) freel[nfree + wave_rank(fb)] = sid;
-            nbox += (uint32_t)__popcll(bb);
-            nsph += (uint32_t)__popcll(sb);
-            nfree += (uint32_t)__popcll(fb);
+            // a finished ray leaves its slot: with a hit, its payload record waits for the shading of that TYPE of primitive
+            const bool toshade = done && has_hit;
+            bool shb = false;
+            if (toshade) {
+                pay_st(pid, P_HIT, __uint_as_float(hit | ((uint32_t)(face + 1) << 8)));
+                shb = lg[hit].type == 1;
+            }
+            PT_WSTAT(20, __popcll(__ballot(toshade))); PT_WSTAT(21, __popcll(__ballot(done)));
+            PT_WSTAT(22, __popcll(__ballot(more))); PT_WSTAT(23, __popcll(__ballot(more && won)));
+            PT_PHASE(9);
+            {
+                const u64 bb = __ballot(more && nbx), sb = __ballot(more && !nbx), fb = __ballot(done);
+                const u64 hb = __ballot(toshade && shb), hs = __ballot(toshade && !shb), pb = __ballot(done && !has_hit);
+                if (more) {
+                    const uint32_t pos = nbx ? nbox + wave_rank(bb) : (uint32_t)R - 1u - (nsph + wave_rank(sb));
+                    xstack[pos] = (unsigned char)sid;
+                }
+                if (done) freel[nfree + wave_rank(fb)] = (unsigned char)sid;
+                if (toshade) {
+                    const uint32_t pos = shb ? nshb + wave_rank(hb) : (uint32_t)NP - 1u - (nshs + wave_rank(hs));
+                    shstack[pos] = (unsigned char)pid;
+                }
+                if (done && !has_hit) pfree[npfree + wave_rank(pb)] = (unsigned char)pid;
+                nbox += (uint32_t)__popcll(bb);
+                nsph += (uint32_t)__popcll(sb);
+                nfree += (uint32_t)__popcll(fb);
+                nshb += (uint32_t)__popcll(hb); nshs += (uint32_t)__popcll(hs); npfree += (uint32_t)__popcll(pb);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            continue;
+        }
+
+        // ==================================================================== SHADE (hits on one type of primitive, any levels)
+        PT_PHASE(8);
+        {
+            const bool hbx = act == 4;
+            const uint32_t have = hbx ? nshb : nshs;
+            const uint32_t cnt = have < 64u ? have : 64u;
+            const bool valid = lane < cnt;
+            if (hbx) nshb -= cnt; else nshs -= cnt;
+            PT_WSTAT(hbx ? 26 : 28, 1); PT_WSTAT(hbx ? 27 : 29, cnt);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");            // payload stores of earlier groups have landed ...
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");            // ... before they are read back through the same L1
+            uint32_t pid = 0u, pv = 0u, level = 0u, hf = 0u;
+            f3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(0, 0, 0), P = mk(0, 0, 0), N = mk(0, 0, 0);
+            if (valid) {
+                pid = shstack[hbx ? have - cnt + lane : (uint32_t)NP - 1u - (have - cnt + lane)];
+                thr = mk(pay_ld(pid, P_TX), pay_ld(pid, P_TY), pay_ld(pid, P_TZ));
+                pv = __float_as_uint(pay_ld(pid, P_PV));
+                level = __float_as_uint(pay_ld(pid, P_LEVEL));
+                d = mk(pay_ld(pid, P_DX), pay_ld(pid, P_DY), pay_ld(pid, P_DZ));
+                P = mk(pay_ld(pid, P_PX), pay_ld(pid, P_PY), pay_ld(pid, P_PZ));
+                hf = __float_as_uint(pay_ld(pid, P_HIT));
+                if (!hbx) N = mk(pay_ld(pid, P_NX), pay_ld(pid, P_NY), pay_ld(pid, P_NZ));
+            }
+            const uint32_t hit = hf & 0xFFu;
+            const int face = (int)((hf >> 8) & 7u) - 1;
+            bool alive = false;
+            if (valid) {
+                const uint32_t slot = a.batch > 1u ? pv >> 24 : 0u, pixel = pv & a.pix_mask;
+                const MatRec m = lm[lg[hit].mat];
+                if (level + 1u >= D && !(m.emittance > 0.0f)) {
+                    alive = true;                                             // depth exhausted: alive, contributes 0
+                } else {
+                    const uint32_t iteration = a.iteration + slot;
+                    uint32_t st = lcg_seed(stream_seed(pixel, iteration, 1u + level));
+                    st = lcg_next(st); const float u_sel = u01(st);
+                    st = lcg_next(st); const float xi1 = u01(st);
+                    st = lcg_next(st); const float xi2 = u01(st);
+                    f3 Lr = mk(0.0f, 0.0f, 0.0f);
+                    int code;
+                    if (hbx) code = scatter_box(m, P, face, frames + 3 * hit, u_sel, xi1, xi2, o, d, thr, Lr);
+                    else code = scatter(m, P, N, u_sel, xi1, xi2, o, d, thr, Lr);
+                    if (code == 3) {
+                        float *base = reinterpret_cast<float *>((uintptr_t)((unsigned long long)park[0] | ((unsigned long long)park[1] << 32)));
+                        size_t off = (size_t)pixel * 3;
+                        if (a.batch > 1u) {
+                            const uint32_t W = park[4];
+                            const uint32_t y = (uint32_t)(((unsigned long long)pixel * park[6]) >> park[7]);
+                            const uint32_t x = pixel - y * W;
+                            const uint32_t ly = (uint32_t)(((unsigned long long)(y - park[5]) * park[8]) >> park[9]);
+                            off = (size_t)slot * (size_t)((unsigned long long)park[2] | ((unsigned long long)park[3] << 32)) + (size_t)(ly * W + x) * 3;
+                        }
+                        float *px = base + off;
+                        (void)unsafeAtomicAdd(px, Lr.x); (void)unsafeAtomicAdd(px + 1, Lr.y); (void)unsafeAtomicAdd(px + 2, Lr.z);
+                        emitted++;
+                    }
+                    alive = code <= 2;
+                }
+            }
+            if (alive) atomicAdd(&lsurv[level + 1u], 1u);
+            // ---------------------------------------------------------------- the payload records are free again; survivors wait for their next bounce
+            if (valid) pfree[npfree + lane] = (unsigned char)pid;
+            npfree += cnt;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-        }
-        const bool onward = alive && level + 1u < D;
-        const u64 ob = __ballot(onward);
-        if (ob) {
-            const uint32_t n = (uint32_t)__popcll(ob);
-            if (sp + n > STK) { if (lane == 0) *pa.error = 2u; }          // never: at most 63 + R rays can wait
-            else {
-                if (onward) {
-                    const uint32_t off = woff + sp + wave_rank(ob);
-                    ring_st(off, 0, o.x); ring_st(off, 1, o.y); ring_st(off, 2, o.z);
-                    ring_st(off, 3, d.x); ring_st(off, 4, d.y); ring_st(off, 5, d.z);
-                    ring_st(off, 6, thr.x); ring_st(off, 7, thr.y); ring_st(off, 8, thr.z);
-                    ring_st(off, 9, __uint_as_float(pv));
-                    ring_st(off, 10, __uint_as_float(level + 1u));
+            const bool onward = alive && level + 1u < D;
+            if (__any(onward)) {
+                // the stack by the walk ahead of the scattered ray (rays the kernel will not walk: the short one)
+                const GridArgs &lga = *reinterpret_cast<const GridArgs *>(ctrl + 100);
+                uint32_t wlen = 0u;
+                if (onward && grid_walk_sane(lga, o, d)) wlen = grid_walk_length(lga, o, d, mk(guarded_rcp(d.x), guarded_rcp(d.y), guarded_rcp(d.z)));
+                const uint32_t bin = wlen <= lga.bin1 ? 0u : wlen <= lga.bin2 ? 1u : 2u;
+                const u64 b0 = __ballot(onward && bin == 0u), b1 = __ballot(onward && bin == 1u), b2 = __ballot(onward && bin == 2u);
+                const uint32_t n0 = (uint32_t)__popcll(b0), n1 = (uint32_t)__popcll(b1), n2 = (uint32_t)__popcll(b2);
+                if (sp0 + n0 > STK || sp1 + n1 > STK || sp2 + n2 > STK) { if (lane == 0) *pa.error = 2u; }      // never: see STK
+                else {
+                    if (onward) {
+                        const uint32_t at = bin == 0u ? sp0 + wave_rank(b0) : bin == 1u ? sp1 + wave_rank(b1) : sp2 + wave_rank(b2);
+                        const uint32_t off = woff + bin * (kSFields * STK) + at;
+                        ring_st(off, 0, o.x); ring_st(off, 1, o.y); ring_st(off, 2, o.z);
+                        ring_st(off, 3, d.x); ring_st(off, 4, d.y); ring_st(off, 5, d.z);
+                        ring_st(off, 6, thr.x); ring_st(off, 7, thr.y); ring_st(off, 8, thr.z);
+                        ring_st(off, 9, __uint_as_float(pv));
+                        ring_st(off, 10, __uint_as_float(level + 1u));
+                    }
+                    sp0 += n0; sp1 += n1; sp2 += n2;
                 }
-                sp += n;
             }
         }
     }
@@ -656,36 +735,40 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
 
 // ------------------------------------------------------------------ host side ---------
 namespace {
-struct WideShape { int waves, slots; };
-// variant -> block shape.  One block per CU; the waves share the CU's LDS: tables + grid + waves x (14 x slots + the two pair buffers) dwords
-constexpr WideShape kShapes[3] = {{16, 104}, {12, 144}, {8, 232}};
+struct WideShape { int waves, slots, payload; };
+// variant -> block shape.  One block per CU; the waves share the CU's LDS: tables + grid + waves x (12 x slots + the byte lists + the
+// two pair buffers).  3: what variant 0 falls back to when a large grid leaves less room.
+constexpr WideShape kShapes[4] = {{16, 112, 240}, {12, 144, 256}, {8, 192, 256}, {16, 80, 208}};
 
-template <int WAVES, int R>
-const void *wide_fn() { return reinterpret_cast<const void *>(&k_path_w<WAVES, R>); }
+template <int WAVES, int R, int NP>
+const void *wide_fn() { return reinterpret_cast<const void *>(&k_path_w<WAVES, R, NP>); }
 const void *wide_fn_of(int v) {
-    return v == 1 ? wide_fn<12, 144>() : v == 2 ? wide_fn<8, 232>() : wide_fn<16, 104>();
+    return v == 1 ? wide_fn<12, 144, 256>() : v == 2 ? wide_fn<8, 192, 256>() : v == 3 ? wide_fn<16, 80, 208>() : wide_fn<16, 112, 240>();
 }
-int clamp_variant(int v) { return v < 0 || v > 2 ? 0 : v; }
+int clamp_variant(int v) { return v < 0 || v > 3 ? 0 : v; }
 }  // namespace
 
 hipError_t wide_setup(int variant, int G, int M, uint32_t grid_bytes, WideLayout *out) {
     const int v = clamp_variant(variant);
     const WideShape s = kShapes[v];
-    const uint32_t lds = tables_bytes(G, M, true) + grid_bytes + (uint32_t)s.waves * (14u * (uint32_t)s.slots + kBufA + kBufC) * 4u;
+    const uint32_t lds = tables_bytes(G, M, true) + grid_bytes +
+                         (uint32_t)s.waves * (12u * (uint32_t)s.slots + (2u * (uint32_t)s.slots + 2u * (uint32_t)s.payload) / 4u + kBufA + kBufC) * 4u;
     out->waves_per_block = (uint32_t)s.waves;
     out->slots_per_wave = (uint32_t)s.slots;
-    out->stack_slots = (uint32_t)((s.slots + 64 + 63) / 64 * 64);
+    out->payload_per_wave = (uint32_t)s.payload;
+    out->stack_slots = (uint32_t)((s.payload + 64 * (int)kWalkBins + 63) / 64 * 64);
     out->lds_bytes = lds;
-    if (lds > 160u * 1024u) return hipErrorInvalidValue;        // the tables leave no room for this shape (the caller falls back)
+    if (lds > 160u * 1024u) return hipErrorInvalidValue;        // the tables leave no room for this shape (the caller tries the next)
     return hipFuncSetAttribute(wide_fn_of(v), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 void wide_launch(int variant, int grid, uint32_t lds, hipStream_t st, const SegArgs &a, const PathArgs &pa, const GridArgs &ga,
                  const GeomRec *g, const MatRec *m, const FaceFrame *frames) {
     switch (clamp_variant(variant)) {
-    case 1: hipLaunchKernelGGL((k_path_w<12, 144>), dim3(grid), dim3(12 * 64), lds, st, a, pa, ga, g, m, frames); break;
-    case 2: hipLaunchKernelGGL((k_path_w<8, 232>), dim3(grid), dim3(8 * 64), lds, st, a, pa, ga, g, m, frames); break;
-    default: hipLaunchKernelGGL((k_path_w<16, 104>), dim3(grid), dim3(16 * 64), lds, st, a, pa, ga, g, m, frames); break;
+    case 1: hipLaunchKernelGGL((k_path_w<12, 144, 256>), dim3(grid), dim3(12 * 64), lds, st, a, pa, ga, g, m, frames); break;
+    case 2: hipLaunchKernelGGL((k_path_w<8, 192, 256>), dim3(grid), dim3(8 * 64), lds, st, a, pa, ga, g, m, frames); break;
+    case 3: hipLaunchKernelGGL((k_path_w<16, 80, 208>), dim3(grid), dim3(16 * 64), lds, st, a, pa, ga, g, m, frames); break;
+    default: hipLaunchKernelGGL((k_path_w<16, 112, 240>), dim3(grid), dim3(16 * 64), lds, st, a, pa, ga, g, m, frames); break;
     }
 }
 

@@ -646,7 +646,7 @@ struct PathArgs {
     uint32_t turn_limit;             // scheduling turns a wave may take before it gives up with error 3 (2^24: never reached; tests lower it)
     float qscale, slack_max;         // k_path_w: candidate keys carry floor(entry distance * qscale); largest GeomRec::slack of the scene
 };
-constexpr uint32_t kWPayload = 11;   // k_path_w: floats per ray slot parked in global memory (throughput, pixel word, level, best hit's P and N)
+constexpr uint32_t kWPayload = 15;   // k_path_w: floats per payload record in global memory (throughput, pixel word, level, best hit's P and N, direction, hit | face)
 
 // k_path_w's spatial index: a uniform grid over the SMALL analytic primitives (host: build_grid, pt_api.hip).  A ray
 // walks the cells it crosses (3D-DDA) and only the primitives listed there have their own bounds tested; primitives
@@ -668,7 +668,9 @@ struct GridArgs {
     uint32_t ncells, nrefs, nbig;
     uint32_t blob_bytes;             // multiple of 16
     const unsigned char *blob;       // device copy
+    uint32_t bin1, bin2;             // survivors wait for their next bounce sorted by the length of their walk in cells: <= bin1, <= bin2, longer
 };
+constexpr uint32_t kWalkBins = 3;
 
 // One ray's walk through the grid: the state a lane keeps, how it starts and how it steps.  Host-callable: the grid
 // probe of the CPU-side tests (pt_debug_grid_probe) runs these very functions over the host copy of the blob.
@@ -741,6 +743,22 @@ __host__ __device__ __forceinline__ void grid_walk_step(GridWalk &w) {
 // a reference (GridArgs) is new to a ray in a cell entered with `emask`
 __host__ __device__ __forceinline__ bool grid_ref_is_new(uint32_t ref, uint32_t emask) { return ((((ref >> 8) & 0x3Fu) | 0x40u) & emask) != 0u; }
 
+// cells the walk of a ray will visit, estimated: 1 + the cell boundaries its span inside the grid's box crosses, counted as
+// the span's extent in cell units per axis (off by at most one and a half cells; 0: the ray misses the box).  k_path_w sorts the
+// survivors of a bounce by it, so that the rays of a FRESH group walk about equally far and the walk's trips run on full waves.
+__host__ __device__ __forceinline__ uint32_t grid_walk_length(const GridArgs &ga, f3 o, f3 d, f3 inv) {
+    const float gx0 = ga.gmin[0], gy0 = ga.gmin[1], gz0 = ga.gmin[2];
+    const float gx1 = __builtin_fmaf((float)ga.n[0], ga.h[0], gx0), gy1 = __builtin_fmaf((float)ga.n[1], ga.h[1], gy0), gz1 = __builtin_fmaf((float)ga.n[2], ga.h[2], gz0);
+    const float ax0 = (gx0 - o.x) * inv.x, ax1 = (gx1 - o.x) * inv.x;
+    const float ay0 = (gy0 - o.y) * inv.y, ay1 = (gy1 - o.y) * inv.y;
+    const float az0 = (gz0 - o.z) * inv.z, az1 = (gz1 - o.z) * inv.z;
+    const float t0 = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fmaxf(fminf(az0, az1), 0.0f));
+    const float t1 = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fmaxf(az0, az1));
+    if (!(t0 <= t1)) return 0u;
+    const float per_t = __builtin_fmaf(fabsf(d.z), ga.inv_h[2], __builtin_fmaf(fabsf(d.y), ga.inv_h[1], fabsf(d.x) * ga.inv_h[0]));
+    return 1u + (uint32_t)fminf((t1 - t0) * per_t, 1000.0f);
+}
+
 // may the ray be walked at all?  finite, a direction of sane length, the origin within `reach` of the grid's centre
 __host__ __device__ __forceinline__ bool grid_walk_sane(const GridArgs &ga, f3 o, f3 d) {
     return fabsf(o.x - ga.centre[0]) <= ga.reach && fabsf(o.y - ga.centre[1]) <= ga.reach && fabsf(o.z - ga.centre[2]) <= ga.reach &&
@@ -791,7 +809,7 @@ void path_launch(bool mesh, int grid, uint32_t lds_bytes, hipStream_t stream, co
                  const GeomRec *geoms, const MatRec *mats, const QTables &qt);
 
 // k_path_w (pt_k_wide.hip): `variant` picks the block shape; the layout says what it needs
-struct WideLayout { uint32_t waves_per_block, slots_per_wave, stack_slots, lds_bytes; };
+struct WideLayout { uint32_t waves_per_block, slots_per_wave, payload_per_wave, stack_slots, lds_bytes; };
 hipError_t wide_setup(int variant, int G, int M, uint32_t grid_bytes, WideLayout *out);
 void wide_launch(int variant, int grid, uint32_t lds_bytes, hipStream_t stream, const SegArgs &a, const PathArgs &pa, const GridArgs &ga,
                  const GeomRec *geoms, const MatRec *mats, const FaceFrame *frames);

@@ -22,8 +22,9 @@ print("CELLS chunks per 64 ray-bounces %.3f at %.1f lanes (references read per r
 print("BOUNDS cube chunks per 64 ray-bounces %.3f at %.1f lanes; sphere chunks %.3f at %.1f lanes" % (s[10] / per, d(s[11], s[10]), s[12] / per, d(s[13], s[12])))
 print("candidates per ray %.2f; overflowed or unwalked rays %d" % (d(s[14] , live) + 0.0, s[15]))
 print("TEST cube groups per 64 ray-bounces %.3f at %.1f lanes; sphere groups %.3f at %.1f lanes; exact tests per ray %.2f" % (s[16] / per, d(s[17], s[16]), s[18] / per, d(s[19], s[18]), d(s[17] + s[19], live)))
+print("SHADE cube-hit groups per 64 ray-bounces %.3f at %.1f lanes; sphere-hit groups %.3f at %.1f lanes" % (s[26] / per, d(s[27], s[26]), s[28] / per, d(s[29], s[28])))
 print("done lanes per TEST group %.1f, shaded %.1f; requeued %.1f (of them after a win %.1f)" % (d(s[21], s[16] + s[18]), d(s[20], s[16] + s[18]), d(s[22], s[16] + s[18]), d(s[23], s[16] + s[18])))
 ph = (C.c_ulonglong * 16)(); pkg.lib().pt_debug_phase_cycles(ph)
 ph = [int(v) for v in ph][:10]; tot = float(sum(ph)) or 1.0
-names = ["schedule", "fresh load + big primitives", "walk", "cells", "bounds", "select", "test load + exact test", "next candidate", "shading", "requeue + survivors"]
+names = ["schedule", "fresh load + big primitives", "walk", "cells", "bounds", "select", "test load + exact test", "next candidate", "shade", "requeue"]
 print("phase clock (share of the waves' cycles): " + ", ".join("%s %.1f%%" % (n, 100.0 * v / tot) for n, v in zip(names, ph)))
