@@ -215,8 +215,9 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events in the timed region")
     ap.add_argument("--chunk-rays", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
-    ap.add_argument("--ordering", type=int, default=2, help="0 = stable compaction (library default), 1 = typed work queues, one launch per bounce (<= 32 primitives), "
-                                                             "2 = whole paths, one launch per group: k_path_q (<= 32 primitives) / k_path_w (33..256 analytic primitives)")
+    ap.add_argument("--ordering", type=int, default=None, help="0 = stable compaction (library default), 1 = typed work queues, one launch per bounce (<= 32 primitives), "
+                                                             "2 = whole paths, one launch per group: k_path_q (<= 32 primitives) / k_path_w (33..256 analytic primitives). "
+                                                             "Default: 2; with --direct-light 0 (the per-bounce kernels resolve a shadow ray inline and are the faster form there)")
     ap.add_argument("--wide-variant", type=int, default=0, help="k_path_w block shape (A/B switch, results identical)")
     ap.add_argument("--cluster-size", type=int, default=0, help="members per spatial cluster for scenes of 33..256 primitives (0 = default)")
     ap.add_argument("--grid-density", type=int, default=0, help="k_path_w: cells of its uniform grid per small primitive (0 = default 4)")
@@ -235,6 +236,8 @@ def main():
     ap.add_argument("--dump-image", default="", help="rank 0 writes the frame it holds after the per-frame exchange (float32 .npy, H x W x 3): parity tests of the N > 1 path")
     ap.add_argument("--repeats", type=int, default=7, help="the exact K-step timed pass is repeated this many times; value = the median pass")
     args = ap.parse_args()
+    if args.ordering is None:
+        args.ordering = 0 if args.direct_light else 2
 
     if args.gpus > 1 and "RANK" not in os.environ:
         # not launched by torchrun: start the N ranks as a CHILD (nothing in this process has touched the GPU, and
@@ -420,8 +423,10 @@ def main():
         # which kernel family rendered (mirrors pt_upload_scene's choice)
         if args.ordering == 2 and not args.direct_light and nprims <= 32:
             kernel = "k_path_q (whole paths, one launch per group: generate + cull + exact tests + scatter + accumulate; rays between bounces on per-wave stacks)"
+        elif args.ordering == 2 and args.direct_light and nprims <= 32 and not meshes:
+            kernel = "k_path_q<NEE> (whole paths, one launch per group; the shadow ray of a diffuse hit is a record of the same typed queues, resolved before the scattered ray goes on)"
         elif args.ordering == 2 and not args.direct_light and nprims <= 256 and not meshes:
-            kernel = "k_path_w (whole paths, one launch per group, 33..256 primitives: cluster culling, dense (ray, cluster) pairs, type-pure exact tests, shading; rays between bounces on per-wave stacks)"
+            kernel = "k_path_w (whole paths, one launch per group, 33..256 primitives: grid walk, dense (ray, cell reference) and (ray, primitive) pairs, type-pure exact tests, shading stage by hit type; rays between bounces on per-wave stacks sorted by walk length)"
         elif args.ordering in (1, 2) and not args.direct_light and nprims <= 32:
             kernel = "k_bounce_q (typed work queues, one launch per bounce)"
         else:

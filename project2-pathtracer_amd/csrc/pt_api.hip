@@ -40,6 +40,7 @@ struct pt_context {
     bool cull = true;                // AABB candidate culling in front of the exact tests (cfg.culling == 0)
     bool queue = false;              // typed work-queue kernel (cfg.ordering == 1 or 2; LDS geometry, G <= 32)
     bool pathq = false;              //   cfg.ordering == 2: whole paths in one launch (k_path_q), per-wave stacks instead of pools
+    bool pathq_nee = false;          //   ... with direct_light (k_path_q<NEE>: shadow rays are records of the same queues); the parity hooks keep k_bounce_seg<NEE>
     bool pathw = false;              // cfg.ordering == 2 with 33..256 analytic primitives: whole paths, dense pairs (k_path_w)
     float *d_arena = nullptr;        //   [grid_path * kWaves][kSFields][kStack]: the waves' ray stacks
     uint32_t *d_tickets = nullptr;   //   [kTicketCtrs][kTicketStride]
@@ -52,6 +53,9 @@ struct pt_context {
     float wide_qscale = 1.0f, wide_slack = 0.0f;
     GridArgs grid;                   //   k_path_w: the uniform grid over the small primitives (build_grid)
     unsigned char *d_grid = nullptr; //   its blob: cells | refs | big list
+    float *d_tap = nullptr;          // parity hook of the whole-path kernels (pt_debug_trace_pool): where the rays entering bounce tap_level go
+    uint32_t *d_tap_count = nullptr;
+    uint32_t tap_level = 0, tap_cap = 0;
     uint32_t turn_limit = 0;         // whole-path kernels: explicit guard against a wave that never finishes (0 = by launch size; pt_debug_set_turn_limit)
     int occ_bounce = 2;              // resident blocks per CU of the per-bounce kernel in use
     uint32_t lds_path = 0;
@@ -532,11 +536,13 @@ int enqueue_iterations(pt_context *c, uint32_t iteration, uint32_t batch, int st
         a.iteration = iteration; a.n_own = c->n_own; a.cam = c->cam; a.bank = c->bank; a.pix_mask = c->pix_mask;
         a.n_rays = n_rays; a.batch = batch; a.planes = c->d_planes; a.plane_stride = (size_t)c->n_own * 3;
         a.nbc = c->nbc; a.nsc = c->nsc; a.cluster_bytes = c->cluster_bytes;
+        a.lights = c->d_lights; a.nlights = c->nlights;
         PathArgs pa;
         memset(&pa, 0, sizeof pa);
         pa.arena = c->d_arena; pa.arena_bytes = c->arena_bytes < (1ull << 32) ? (uint32_t)c->arena_bytes : 0u;
         pa.depth = (uint32_t)D; pa.ticket = c->d_tickets; pa.error = &c->d_sync->error;
         pa.qscale = c->wide_qscale; pa.slack_max = c->wide_slack;
+        pa.tap = c->d_tap; pa.tap_count = c->d_tap_count; pa.tap_level = c->tap_level; pa.tap_cap = c->tap_cap;
         const uint64_t waves = (uint64_t)c->grid_path * (uint64_t)c->path_waves;
         {   // job size: about 48 jobs per wave of the launch, whole groups, 64 .. kJobMax rays
             const uint64_t per_wave = (uint64_t)n_rays / (waves * 48u);
@@ -561,10 +567,10 @@ int enqueue_iterations(pt_context *c, uint32_t iteration, uint32_t batch, int st
         {
             Scoped s(c, 1);
             if (c->pathw) wide_launch(c->wide_variant, c->grid_path, c->lds_path, c->stream, a, pa, c->grid, c->d_geoms, c->d_mats, c->d_frames);
-            else path_launch(c->queue_mesh, c->grid_path, c->lds_path, c->stream, a, pa, c->d_geoms, c->d_mats, qt);
+            else path_launch(c->queue_mesh, c->pathq_nee, c->grid_path, c->lds_path, c->stream, a, pa, c->d_geoms, c->d_mats, qt);
             HIPCHK(hipGetLastError());
         }
-        if (batch > 1u) { int rc = enqueue_fold(c, batch); if (rc) return rc; }
+        if (batch > 1u || c->nee) { int rc = enqueue_fold(c, batch); if (rc) return rc; }
         c->counts_pending = true;
         return PT_OK;
     }
@@ -980,7 +986,9 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     HIPCHK(hipMalloc(&c->d_display, (size_t)W * H * sizeof(uchar4)));
     HIPCHK(hipMemcpy(c->d_geoms, g.data(), (size_t)G * sizeof(GeomRec), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_mats, m.data(), (size_t)M * sizeof(MatRec), hipMemcpyHostToDevice));
-    if (c->queue) {
+    // direct_light with ordering = 2 on a scene the typed queues take (<= 32 analytic primitives, no meshes): whole paths in one launch
+    c->pathq_nee = c->nee && c->cull && c->cfg.ordering == 2 && G <= 32 && !have_mesh;
+    if (c->queue || c->pathq_nee) {
         // per box primitive and axis: unit normal + the two tangent frames scatter() would derive per ray; evaluated
         // here with the kernels' own functions (pt_device.hpp is host-callable, same -ffp-contract=off build)
         std::vector<FaceFrame> fr((size_t)G * 3);
@@ -1015,15 +1023,16 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         HIPCHK(hipMemcpy(c->d_cull, cr.data(), cr.size() * sizeof(CullRec), hipMemcpyHostToDevice));
     }
     // ordering = 2: whole paths in one launch -- a persistent grid of its own and the waves' level rings
-    c->pathq = c->queue && c->cfg.ordering == 2 && !c->nee;
+    c->pathq = (c->queue && c->cfg.ordering == 2 && !c->nee) || c->pathq_nee;
     if (c->pathq) {
         c->lds_path = p_lds_bytes(G, M);
         int occ = 0;
-        HIPCHK(path_setup(c->queue_mesh, c->lds_path, &occ));
+        HIPCHK(path_setup(c->queue_mesh, c->pathq_nee, c->lds_path, &occ));
         if (c->cfg.blocks_per_cu > 0) occ = c->cfg.blocks_per_cu;
         c->grid_path = c->n_cu * occ;
         c->path_waves = (uint32_t)kWaves;
-        c->arena_bytes = (size_t)c->grid_path * kWaves * (size_t)kSFields * kStack * sizeof(float);
+        const size_t extra = c->pathq_nee ? kNeeExtraFields : 0;
+        c->arena_bytes = (size_t)c->grid_path * kWaves * (((size_t)kSFields + extra) * kStack + ((size_t)kPParked + extra) * kPCap) * sizeof(float);
         HIPCHK(hipMalloc(&c->d_arena, c->arena_bytes));
         HIPCHK(hipMalloc(&c->d_tickets, (size_t)kTicketCtrs * kTicketStride * sizeof(uint32_t)));
     }
@@ -1048,7 +1057,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         }
         c->lds_path = wl.lds_bytes;
         c->path_waves = wl.waves_per_block;
-        c->grid_path = c->n_cu * (c->cfg.blocks_per_cu > 0 ? 1 : 1);
+        c->grid_path = c->n_cu;
         c->wide_stack = wl.stack_slots; c->wide_slots = wl.slots_per_wave;
         {   // candidate keys: conservative entry distance in 250 steps of the scene's diagonal; the re-check slack of the scene
             double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, smax = 0.0;
@@ -1411,12 +1420,50 @@ int pt_debug_trace_pool(pt_context *c, int iteration, int bounces, int *count, f
     float *saved = c->image, *scratch = nullptr;
     HIPCHK(hipMalloc(&scratch, (size_t)c->W * c->H * 3 * sizeof(float)));
     HIPCHK(hipMemsetAsync(scratch, 0, (size_t)c->W * c->H * 3 * sizeof(float), c->stream));
+    // ordering = 2: the whole-path kernel itself is probed -- the rays that survive bounce `bounces` - 1 leave through a tap instead
+    // of going on (pool 0 = the camera rays and the pool after the last bounce keep the per-bounce kernels: a whole path has neither)
+    const bool tapped = (c->pathq || c->pathw) && !c->nee && bounces >= 1 && bounces < c->cfg.max_depth;
+    if (tapped) {
+        c->tap_cap = c->n_own; c->tap_level = (uint32_t)bounces;
+        HIPCHK(hipMalloc(&c->d_tap, (size_t)c->tap_cap * 10 * sizeof(float)));
+        HIPCHK(hipMalloc(&c->d_tap_count, sizeof(uint32_t)));
+        HIPCHK(hipMemsetAsync(c->d_tap_count, 0, sizeof(uint32_t), c->stream));
+    }
     c->image = scratch;
-    int rc = enqueue_iterations(c, (uint32_t)iteration, 1u, bounces);
+    int rc = enqueue_iterations(c, (uint32_t)iteration, 1u, tapped ? -1 : bounces);
     c->image = saved;
-    if (rc) { (void)hipFree(scratch); return rc; }
+    c->tap_level = 0;
+    if (rc) { (void)hipFree(scratch); if (tapped) { (void)hipFree(c->d_tap); (void)hipFree(c->d_tap_count); c->d_tap = nullptr; c->d_tap_count = nullptr; } return rc; }
     HIPCHK(hipStreamSynchronize(c->stream));
     (void)hipFree(scratch);
+    if (tapped) {
+        uint32_t n = 0;
+        std::vector<float> rec((size_t)c->tap_cap * 10);
+        hipError_t e1 = hipMemcpy(&n, c->d_tap_count, sizeof n, hipMemcpyDeviceToHost);
+        hipError_t e2 = hipMemcpy(rec.data(), c->d_tap, rec.size() * sizeof(float), hipMemcpyDeviceToHost);
+        SyncBlock after;
+        hipError_t e3 = hipMemcpy(&after, c->d_sync, sizeof after, hipMemcpyDeviceToHost);
+        (void)hipFree(c->d_tap); (void)hipFree(c->d_tap_count);
+        c->d_tap = nullptr; c->d_tap_count = nullptr;
+        HIPCHK(e1); HIPCHK(e2); HIPCHK(e3);
+        const uint32_t live = c->bank ? after.counts_b[bounces] : after.counts[bounces];
+        c->bank = bank_saved;
+        HIPCHK(hipMemcpy(c->d_sync, &snapshot, sizeof snapshot, hipMemcpyHostToDevice));
+        c->counts_pending = pending;
+        if (n > c->tap_cap || n != live) { pth::set_error("pt_debug_trace_pool: the tap holds %u rays, the live counter of bounce %d says %u", n, bounces, live); return PT_ERR_HIP; }
+        // the waves met the rays in their own order: generation order = pixel order
+        const size_t cap = c->tap_cap;
+        std::vector<uint32_t> order(n);
+        for (uint32_t i = 0; i < n; ++i) order[i] = i;
+        auto pix = [&](uint32_t i) { uint32_t v; memcpy(&v, &rec[9 * cap + i], 4); return v & c->pix_mask; };
+        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return pix(x) < pix(y); });
+        float *dst[9] = {ox, oy, oz, dx, dy, dz, tr, tg, tb};
+        for (int f = 0; f < 9; ++f)
+            if (dst[f]) for (uint32_t i = 0; i < n; ++i) dst[f][i] = rec[(size_t)f * cap + order[i]];
+        if (pixel) for (uint32_t i = 0; i < n; ++i) memcpy(&pixel[i], &rec[9 * cap + order[i]], 4);
+        if (count) *count = (int)n;
+        return check_device_error(c);
+    }
     SyncBlock after;
     HIPCHK(hipMemcpy(&after, c->d_sync, sizeof after, hipMemcpyDeviceToHost));
     const bool fused = bounces != 0;

@@ -5,10 +5,21 @@
 namespace ptk {
 
 // MESH: the scene holds MESH primitives with triangles (they share the spheres' stack; the traversal needs registers the
-// common variant must not pay for)
-template <bool MESH>
-__global__ __launch_bounds__(kBlock, 4) void k_path_q(SegArgs a, PathArgs pa, const GeomRec *__restrict__ geoms,
+// common variant must not pay for).
+// NEE: direct_light (oracle path_bounce / direct_light).  A path is ONE chain of records: at a diffuse hit
+// the shadow ray to the sampled emitter is traced FIRST -- a record like any other, marked, that carries the scattered direction and
+// the geometric factors of the sample in its parked words -- and only when it has been resolved (its nearest hit decides whether
+// the emitter's radiance is added) does the scattered ray itself go on.  The radiance a path gathers rides with it (`acc`, the
+// oracle's L: emitter hits and shadow-ray contributions summed in bounce order from zero) and is added to the path's pixel of its
+// iteration's accumulator plane once, where the path ends -- the same additions in the same order as the per-bounce kernels.
+template <bool MESH, bool NEE>
+__global__ __launch_bounds__(kBlock, MESH ? 4 : NEE ? 5 : 6) void k_path_q(SegArgs a, PathArgs pa, const GeomRec *__restrict__ geoms,
                                                       const MatRec *__restrict__ mats, QTables qt) {
+    // stack / parked fields of the NEE variant beyond the common ones: acc (3), scattered direction (3), cos at the surface,
+    // 1 / pdf of the light sample, squared distance to it.  Level word: level | shadow << 8 | count-emission << 9 | light << 10
+    constexpr uint32_t SF = NEE ? kSFields + 9u : kSFields;
+    constexpr uint32_t PF = NEE ? kPParked + 9u : kPParked;
+    constexpr uint32_t PX = kPParked;                      // where the NEE words start among a record's parked words
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *ctrl = reinterpret_cast<uint32_t *>(smem);   // [1] emitted (block sum), [32..96] survivors per level
     uint32_t *lsurv = ctrl + 32;
@@ -16,7 +27,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_path_q(SegArgs a, PathArgs pa, co
     if (threadIdx.x < 65) lsurv[threadIdx.x] = 0u;
     uint32_t *park = ctrl + 18;
     if (threadIdx.x == 0) {
-        const unsigned long long pl = (unsigned long long)(uintptr_t)(a.batch > 1u ? a.planes : a.image), st = (unsigned long long)a.plane_stride;
+        const unsigned long long pl = (unsigned long long)(uintptr_t)((NEE || a.batch > 1u) ? a.planes : a.image), st = (unsigned long long)a.plane_stride;
         park[0] = (uint32_t)pl; park[1] = (uint32_t)(pl >> 32); park[2] = (uint32_t)st; park[3] = (uint32_t)(st >> 32);
         park[4] = (uint32_t)a.cam.W; park[5] = (uint32_t)a.cam.row_offset; park[6] = a.cam.mW; park[7] = a.cam.shW;
         park[8] = a.cam.mS; park[9] = a.cam.shS;
@@ -39,8 +50,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_path_q(SegArgs a, PathArgs pa, co
     const uint32_t wslot = blockIdx.x * kWaves + wave;
     const uint32_t D = pa.depth;
     float *q = reinterpret_cast<float *>(smem + p_queue_offset(a.G, a.M)) + (size_t)wave * kPCap * kPFields;
-    // the wave's stack: field f of slot s at woff + f * kStack + s
-    const uint32_t wave_floats = kSFields * kStack;
+    // the wave's arena: its stack (field f of slot s at woff + f * kStack + s), then what the queue records park (field f of record r
+    // at poff + f * kPCap + r)
+    const uint32_t wave_floats = SF * kStack + PF * kPCap;
     const bool ub = pa.arena_bytes != 0u;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pa.arena, 0, pa.arena_bytes, 0x00020000);
     const uint32_t woff = wslot * wave_floats;             // in floats (buffer path: arena below 4 GiB)
@@ -50,6 +62,30 @@ __global__ __launch_bounds__(kBlock, 4) void k_path_q(SegArgs a, PathArgs pa, co
     auto ring_st = [&](uint32_t off, uint32_t f, float v) {
         if (ub) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, off * 4u, f * kStack * 4u, 0);
         else pa.arena[(size_t)off + f * kStack] = v;
+    };
+    const uint32_t poff = woff + SF * kStack;
+    auto park_ld = [&](uint32_t pos, uint32_t f) -> float {
+        return ub ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (poff + pos) * 4u, f * kPCap * 4u, 0)) : pa.arena[(size_t)poff + pos + f * kPCap];
+    };
+    auto park_st = [&](uint32_t pos, uint32_t f, float v) {
+        if (ub) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, (poff + pos) * 4u, f * kPCap * 4u, 0);
+        else pa.arena[(size_t)poff + pos + f * kPCap] = v;
+    };
+
+    // radiance -> the path's pixel: of the frame, or of its iteration's accumulator plane (owned rows only)
+    auto splat = [&](uint32_t pv, f3 L) {
+        const uint32_t slot = a.batch > 1u ? pv >> 24 : 0u, pixel = pv & a.pix_mask;
+        float *base = reinterpret_cast<float *>((uintptr_t)((unsigned long long)park[0] | ((unsigned long long)park[1] << 32)));
+        size_t off = (size_t)pixel * 3;
+        if (NEE || a.batch > 1u) {
+            const uint32_t W = park[4];
+            const uint32_t y = (uint32_t)(((unsigned long long)pixel * park[6]) >> park[7]);
+            const uint32_t x = pixel - y * W;
+            const uint32_t ly = (uint32_t)(((unsigned long long)(y - park[5]) * park[8]) >> park[9]);
+            off = (size_t)slot * (size_t)((unsigned long long)park[2] | ((unsigned long long)park[3] << 32)) + (size_t)(ly * W + x) * 3;
+        }
+        float *px = base + off;
+        (void)unsafeAtomicAdd(px, L.x); (void)unsafeAtomicAdd(px + 1, L.y); (void)unsafeAtomicAdd(px + 2, L.z);
     };
 
     uint32_t *bank = a.bank ? a.sync->counts_b : a.sync->counts;
@@ -120,7 +156,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_path_q(SegArgs a, PathArgs pa, co
         if (act == 0 || act == 3) {
             // ---------------------------------------------------------------- FRESH
             f3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(1.0f, 1.0f, 1.0f);
-            uint32_t pv = 0u, level = 0u;
+            uint32_t pv = 0u, level = NEE ? (1u << 9) : 0u;                                // (NEE: the level WORD; a camera ray counts emission)
+            f3 acc = mk(0, 0, 0), nd = mk(0, 0, 0);                                        // NEE only
+            float cos_s = 0.0f, invpdf = 0.0f, dist2 = 0.0f;
             bool valid;
             if (act == 3) {                                                                // camera rays
                 const uint32_t ray = jobpos + lane;
@@ -140,14 +178,19 @@ __global__ __launch_bounds__(kBlock, 4) void k_path_q(SegArgs a, PathArgs pa, co
                 valid = lane < cnt;
                 sp -= cnt;
                 const uint32_t off = woff + sp + lane;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // the wave's own stack stores have landed (vmcnt 0) ...
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");        // ... before they are read back through the same L1
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, PT_SELF_SCOPE);        // the wave's own stack stores have landed (vmcnt 0) ...
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, PT_SELF_SCOPE);        // ... before they are read back through the same L1
                 if (valid) {
                     o = mk(ring_ld(off, 0), ring_ld(off, 1), ring_ld(off, 2));
                     d = mk(ring_ld(off, 3), ring_ld(off, 4), ring_ld(off, 5));
                     thr = mk(ring_ld(off, 6), ring_ld(off, 7), ring_ld(off, 8));
                     pv = __float_as_uint(ring_ld(off, 9));
                     level = __float_as_uint(ring_ld(off, 10));
+                    if constexpr (NEE) {
+                        acc = mk(ring_ld(off, 11), ring_ld(off, 12), ring_ld(off, 13));
+                        nd = mk(ring_ld(off, 14), ring_ld(off, 15), ring_ld(off, 16));
+                        cos_s = ring_ld(off, 17); invpdf = ring_ld(off, 18); dist2 = ring_ld(off, 19);
+                    }
                 }
             }
             const CullRay cr = make_cull_ray(o, d);
@@ -189,15 +232,46 @@ __global__ __launch_bounds__(kBlock, 4) void k_path_q(SegArgs a, PathArgs pa, co
                     float *r = q + pos;
                     r[0 * kPCap] = o.x; r[1 * kPCap] = o.y; r[2 * kPCap] = o.z;
                     r[3 * kPCap] = d.x; r[4 * kPCap] = d.y; r[5 * kPCap] = d.z;
+#if PT_P_SPLIT
+                    park_st(pos, 0, thr.x); park_st(pos, 1, thr.y); park_st(pos, 2, thr.z); park_st(pos, 3, __uint_as_float(pv));
+                    r[6 * kPCap] = __uint_as_float(mask);
+                    r[7 * kPCap] = __uint_as_float(next_j | (level << 8));
+#else
                     r[6 * kPCap] = thr.x; r[7 * kPCap] = thr.y; r[8 * kPCap] = thr.z;
                     r[9 * kPCap] = __uint_as_float(pv);
                     r[10 * kPCap] = __uint_as_float(mask);
                     r[11 * kPCap] = __uint_as_float(next_j | (level << 8));
+#endif
+                    if constexpr (NEE) {
+                        park_st(pos, PX + 0, acc.x); park_st(pos, PX + 1, acc.y); park_st(pos, PX + 2, acc.z);
+                        park_st(pos, PX + 3, nd.x); park_st(pos, PX + 4, nd.y); park_st(pos, PX + 5, nd.z);
+                        park_st(pos, PX + 6, cos_s); park_st(pos, PX + 7, invpdf); park_st(pos, PX + 8, dist2);
+                    }
                 }
                 nbox += (uint32_t)__popcll(bb);
                 nsph += (uint32_t)__popcll(sb);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+            }
+            if constexpr (NEE) {
+                // a ray without any candidate: a path ends here with what it has gathered; a shadow ray has simply not reached its
+                // emitter, and the scattered ray it held back goes on (next level, emission not counted after a diffuse event)
+                const bool gone = valid && !push;
+                const bool sh = gone && (level & 0x100u) != 0u;
+                if (gone && !sh && (acc.x != 0.0f || acc.y != 0.0f || acc.z != 0.0f)) splat(pv, acc);
+                const u64 cb = __ballot(sh);
+                if (cb) {
+                    if (sh) {
+                        const uint32_t off = woff + sp + wave_rank(cb);
+                        ring_st(off, 0, o.x); ring_st(off, 1, o.y); ring_st(off, 2, o.z);
+                        ring_st(off, 3, nd.x); ring_st(off, 4, nd.y); ring_st(off, 5, nd.z);
+                        ring_st(off, 6, thr.x); ring_st(off, 7, thr.y); ring_st(off, 8, thr.z);
+                        ring_st(off, 9, __uint_as_float(pv));
+                        ring_st(off, 10, __uint_as_float((level & 0xFFu) + 1u));
+                        ring_st(off, 11, acc.x); ring_st(off, 12, acc.y); ring_st(off, 13, acc.z);
+                    }
+                    sp += (uint32_t)__popcll(cb);                     // (the group came off the stack: at most as many go back)
+                }
             }
             continue;
         }
@@ -214,19 +288,40 @@ __global__ __launch_bounds__(kBlock, 4) void k_path_q(SegArgs a, PathArgs pa, co
 #endif
         f3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(0, 0, 0);
         uint32_t pv = 0u, mask = 0u, level = 0u;
+        f3 acc = mk(0, 0, 0), nd = mk(0, 0, 0);                               // NEE only
+        float cos_s = 0.0f, invpdf = 0.0f, dist2 = 0.0f;
         int j = 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (PT_P_SPLIT || NEE) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, PT_SELF_SCOPE);            // the parked words of earlier groups have landed (vmcnt 0) ...
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, PT_SELF_SCOPE);            // ... before they are read back through the same L1
+        }
         if (valid) {
             const float *r = q + pos;
             o = mk(r[0 * kPCap], r[1 * kPCap], r[2 * kPCap]);
             d = mk(r[3 * kPCap], r[4 * kPCap], r[5 * kPCap]);
+#if PT_P_SPLIT
+            // throughput and pixel word: requested now, used after the test
+            thr = mk(park_ld(pos, 0), park_ld(pos, 1), park_ld(pos, 2));
+            pv = __float_as_uint(park_ld(pos, 3));
+            mask = __float_as_uint(r[6 * kPCap]);
+            const uint32_t jl = __float_as_uint(r[7 * kPCap]);
+#else
             thr = mk(r[6 * kPCap], r[7 * kPCap], r[8 * kPCap]);
             pv = __float_as_uint(r[9 * kPCap]);
             mask = __float_as_uint(r[10 * kPCap]);
             const uint32_t jl = __float_as_uint(r[11 * kPCap]);
+#endif
+            if constexpr (NEE) {
+                acc = mk(park_ld(pos, PX + 0), park_ld(pos, PX + 1), park_ld(pos, PX + 2));
+                nd = mk(park_ld(pos, PX + 3), park_ld(pos, PX + 4), park_ld(pos, PX + 5));
+                cos_s = park_ld(pos, PX + 6); invpdf = park_ld(pos, PX + 7); dist2 = park_ld(pos, PX + 8);
+            }
             j = (int)(jl & 0xFFu);
             level = jl >> 8;
         }
+        const uint32_t lw = level;                                            // NEE: the level word (level | shadow << 8 | count-emission << 9 | light << 10)
+        if constexpr (NEE) level &= 0xFFu;
         __builtin_amdgcn_wave_barrier();
         float best;
         int hit, face = -1;
@@ -283,6 +378,112 @@ __global__ __launch_bounds__(kBlock, 4) void k_path_q(SegArgs a, PathArgs pa, co
         qstat(14, (unsigned long long)__popcll(__ballot(hit >= 0)));
         qstat(7, (unsigned long long)__popcll(__ballot(hit >= 0 && level + 1u >= D)));
 #endif
+        if constexpr (NEE) {
+            // ---------------------------------------------------------------- direct light: shadow rays resolve, paths carry their radiance
+            const bool sh = valid && (lw & 0x100u) != 0u;
+            bool to_stack = false;                                            // this lane's path goes on: (o, d, thr, next level word) below
+            uint32_t next_lw = 0u;
+            if (sh) {
+                // the shadow ray's nearest hit decides (oracle direct_light): the sampled emitter itself, not hidden by a nearer face of it
+                const uint32_t lid = (lw >> 10) & 0xFFu;
+                const float dist = __builtin_sqrtf(dist2);
+                const float tol = 1e-3f * (dist > 1.0f ? dist : 1.0f);
+                if (hit == (int)lid && (best + tol >= dist)) {
+                    const f3 Nh = ((boxbits >> lid) & 1u) ? box_face_normal(lg[lid].xf, face) : N;
+                    const float nl2 = dot(Nh, Nh);
+                    if (nl2 > 0.0f) {
+                        const float cos_l = fabsf(dot(Nh, d)) / __builtin_sqrtf(nl2);
+                        const float geomf = (((cos_s * cos_l) * invpdf) / (PT_PI * dist2)) * (float)a.nlights;
+                        const MatRec ml = lm[lg[lid].mat];
+                        const f3 Le = mk(ml.color[0], ml.color[1], ml.color[2]) * ml.emittance;
+                        const f3 Cc = (thr * Le) * geomf;
+                        acc = mk(acc.x + Cc.x, acc.y + Cc.y, acc.z + Cc.z);
+                    }
+                }
+                d = nd;                                                       // the scattered ray it held back goes on from the same origin
+                next_lw = level + 1u;                                         // (after a diffuse event emission is not counted)
+                to_stack = true;
+            }
+            bool alive = false, ended = valid && !sh && hit < 0;
+            if (valid && !sh && hit >= 0) {
+                const uint32_t slot = a.batch > 1u ? pv >> 24 : 0u, pixel = pv & a.pix_mask;
+                const MatRec m = lm[lg[hit].mat];
+                if (level + 1u >= D && !(m.emittance > 0.0f)) {
+                    alive = true; ended = true;                               // depth exhausted: alive, contributes 0
+                } else {
+                    const uint32_t iteration = a.iteration + slot;
+                    uint32_t st = lcg_seed(stream_seed(pixel, iteration, 1u + level));
+                    st = lcg_next(st); const float u_sel = u01(st);
+                    st = lcg_next(st); const float xi1 = u01(st);
+                    st = lcg_next(st); const float xi2 = u01(st);
+                    const f3 d_in = d;
+                    f3 L = mk(0.0f, 0.0f, 0.0f);
+                    int code = 4;
+                    const bool hb = (boxbits >> hit) & 1u;
+                    const f3 Ng = hb ? box_face_normal(lg[hit].xf, face) : N;     // the geometric normal the light sample is oriented by
+                    if (__any(hb)) { if (hb) code = scatter_box(m, P, face, lf + 3 * hit, u_sel, xi1, xi2, o, d, thr, L); }
+                    if (__any(!hb)) { if (!hb) code = scatter(m, P, N, u_sel, xi1, xi2, o, d, thr, L); }
+                    if (code == 3) {
+                        if (lw & 0x200u) acc = mk(acc.x + L.x, acc.y + L.y, acc.z + L.z);
+                        emitted++;
+                    }
+                    alive = code <= 2;
+                    ended = !alive;
+                    if (alive) {
+                        to_stack = true;
+                        next_lw = (level + 1u) | ((code == 1 || code == 2) ? 0x200u : 0u);
+                        if (code == 0 && a.nlights > 0u) {
+                            // one shadow ray to a point on a random emitter (the reference's getRandomPointOnCube / Sphere)
+                            st = lcg_next(st); const float u_l = u01(st);
+                            st = lcg_next(st); const float seedf = (float)(st & 0xFFFFFFu);
+                            int li = (int)(u_l * (float)a.nlights);
+                            if (li > (int)a.nlights - 1) li = (int)a.nlights - 1;
+                            const int lid = (int)a.lights[li];
+                            f3 Q;
+                            float ipdf;
+                            const bool ok = sample_light(lg[lid].xf, lg[lid].type, seedf, Q, ipdf);
+                            const f3 wv = Q - o;
+                            const float d2 = dot(wv, wv);
+                            if (ok && d2 > 0.0f) {
+                                const float dist = __builtin_sqrtf(d2);
+                                const f3 w = wv * (1.0f / dist);
+                                const f3 n = Ng * (1.0f / __builtin_sqrtf(dot(Ng, Ng)));
+                                const f3 nf = (dot(n, d_in) > 0.0f) ? neg(n) : n;
+                                const float cs = dot(nf, w);
+                                if (cs > 0.0f) {
+                                    nd = d; d = w;                            // the shadow ray first; the scattered direction waits in the record
+                                    cos_s = cs; invpdf = ipdf; dist2 = d2;
+                                    next_lw = level | 0x100u | ((uint32_t)lid << 10);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (alive) atomicAdd(&lsurv[level + 1u], 1u);
+            // a path that ends here leaves what it has gathered in its pixel of its iteration's plane
+            if (ended && (acc.x != 0.0f || acc.y != 0.0f || acc.z != 0.0f)) splat(pv, acc);
+            const u64 ballot = __ballot(to_stack);
+            if (ballot) {
+                const uint32_t n = (uint32_t)__popcll(ballot);
+                if (sp + n > kStack) { if (lane == 0) *pa.error = 2u; }
+                else {
+                    if (to_stack) {
+                        const uint32_t off = woff + sp + wave_rank(ballot);
+                        ring_st(off, 0, o.x); ring_st(off, 1, o.y); ring_st(off, 2, o.z);
+                        ring_st(off, 3, d.x); ring_st(off, 4, d.y); ring_st(off, 5, d.z);
+                        ring_st(off, 6, thr.x); ring_st(off, 7, thr.y); ring_st(off, 8, thr.z);
+                        ring_st(off, 9, __uint_as_float(pv));
+                        ring_st(off, 10, __uint_as_float(next_lw));
+                        ring_st(off, 11, acc.x); ring_st(off, 12, acc.y); ring_st(off, 13, acc.z);
+                        ring_st(off, 14, nd.x); ring_st(off, 15, nd.y); ring_st(off, 16, nd.z);
+                        ring_st(off, 17, cos_s); ring_st(off, 18, invpdf); ring_st(off, 19, dist2);
+                    }
+                    sp += n;
+                }
+            }
+            continue;
+        }
         // shade the hits (the ray's own level is its bounce index)
         bool alive = false;
         if (hit >= 0) {
@@ -320,7 +521,23 @@ __global__ __launch_bounds__(kBlock, 4) void k_path_q(SegArgs a, PathArgs pa, co
         }
         // survivors: counted per level (one LDS atomic for the group); those with bounces left go on the wave's stack
         if (alive) atomicAdd(&lsurv[level + 1u], 1u);
-        const bool onward = alive && level + 1u < D;
+        bool onward = alive && level + 1u < D;
+        if (pa.tap_level != 0u) {                                             // parity hook: the rays entering bounce tap_level leave here
+            const bool tapped = onward && level + 1u == pa.tap_level;
+            const u64 tb = __ballot(tapped);
+            if (tb) {
+                uint32_t base = 0u;
+                if (lane == 0) base = atomicAdd(pa.tap_count, (uint32_t)__popcll(tb));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (tapped) {
+                    float *t = pa.tap + base + wave_rank(tb);
+                    const size_t cap = pa.tap_cap;
+                    t[0 * cap] = o.x; t[1 * cap] = o.y; t[2 * cap] = o.z; t[3 * cap] = d.x; t[4 * cap] = d.y; t[5 * cap] = d.z;
+                    t[6 * cap] = thr.x; t[7 * cap] = thr.y; t[8 * cap] = thr.z; t[9 * cap] = __uint_as_float(pv);
+                }
+            }
+            onward = onward && !tapped;
+        }
         const u64 ballot = __ballot(onward);
         if (ballot) {
             const uint32_t n = (uint32_t)__popcll(ballot);
@@ -337,7 +554,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_path_q(SegArgs a, PathArgs pa, co
                 sp += n;
             }
         }
-    }
+        }
 
     for (int sft = 32; sft > 0; sft >>= 1) emitted += __shfl_down(emitted, sft);
     if (lane == 0 && emitted) atomicAdd(&ctrl[1], emitted);
@@ -347,8 +564,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_path_q(SegArgs a, PathArgs pa, co
 }
 
 // ------------------------------------------------------------------ host side ---------
-hipError_t path_setup(bool mesh, uint32_t lds_bytes, int *blocks_per_cu) {
-    const void *fn = mesh ? reinterpret_cast<const void *>(&k_path_q<true>) : reinterpret_cast<const void *>(&k_path_q<false>);
+hipError_t path_setup(bool mesh, bool nee, uint32_t lds_bytes, int *blocks_per_cu) {
+    const void *fn = nee ? reinterpret_cast<const void *>(&k_path_q<false, true>)
+                         : mesh ? reinterpret_cast<const void *>(&k_path_q<true, false>) : reinterpret_cast<const void *>(&k_path_q<false, false>);
     if (lds_bytes > 64u * 1024u) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -359,10 +577,11 @@ hipError_t path_setup(bool mesh, uint32_t lds_bytes, int *blocks_per_cu) {
     return hipSuccess;
 }
 
-void path_launch(bool mesh, int grid, uint32_t lds, hipStream_t st, const SegArgs &a, const PathArgs &pa,
+void path_launch(bool mesh, bool nee, int grid, uint32_t lds, hipStream_t st, const SegArgs &a, const PathArgs &pa,
                  const GeomRec *g, const MatRec *m, const QTables &qt) {
-    if (mesh) hipLaunchKernelGGL(k_path_q<true>, dim3(grid), dim3(kBlock), lds, st, a, pa, g, m, qt);
-    else hipLaunchKernelGGL(k_path_q<false>, dim3(grid), dim3(kBlock), lds, st, a, pa, g, m, qt);
+    if (nee) hipLaunchKernelGGL((k_path_q<false, true>), dim3(grid), dim3(kBlock), lds, st, a, pa, g, m, qt);
+    else if (mesh) hipLaunchKernelGGL((k_path_q<true, false>), dim3(grid), dim3(kBlock), lds, st, a, pa, g, m, qt);
+    else hipLaunchKernelGGL((k_path_q<false, false>), dim3(grid), dim3(kBlock), lds, st, a, pa, g, m, qt);
 }
 
 #ifdef PT_CULL_STATS

@@ -287,8 +287,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
                 sp2 -= t2; sp1 -= t1; sp0 -= t0;
                 const uint32_t off = woff + (lane < t2 ? 2u * (kSFields * STK) + sp2 + lane
                                              : lane < t2 + t1 ? 1u * (kSFields * STK) + sp1 + (lane - t2) : sp0 + (lane - t2 - t1));
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // the wave's own stack stores have landed (vmcnt 0) ...
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");        // ... before they are read back through the same L1
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, PT_SELF_SCOPE);        // the wave's own stack stores have landed (vmcnt 0) ...
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, PT_SELF_SCOPE);        // ... before they are read back through the same L1
                 if (valid) {
                     o = mk(ring_ld(off, 0), ring_ld(off, 1), ring_ld(off, 2));
                     d = mk(ring_ld(off, 3), ring_ld(off, 4), ring_ld(off, 5));
@@ -641,8 +641,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
             if (hbx) nshb -= cnt; else nshs -= cnt;
             PT_WSTAT(hbx ? 26 : 28, 1); PT_WSTAT(hbx ? 27 : 29, cnt);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");            // payload stores of earlier groups have landed ...
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");            // ... before they are read back through the same L1
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, PT_SELF_SCOPE);            // payload stores of earlier groups have landed ...
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, PT_SELF_SCOPE);            // ... before they are read back through the same L1
             uint32_t pid = 0u, pv = 0u, level = 0u, hf = 0u;
             f3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(0, 0, 0), P = mk(0, 0, 0), N = mk(0, 0, 0);
             if (valid) {
@@ -696,7 +696,23 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
             npfree += cnt;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const bool onward = alive && level + 1u < D;
+            bool onward = alive && level + 1u < D;
+            if (pa.tap_level != 0u) {                                         // parity hook: the rays entering bounce tap_level leave here
+                const bool tapped = onward && level + 1u == pa.tap_level;
+                const u64 tb2 = __ballot(tapped);
+                if (tb2) {
+                    uint32_t base = 0u;
+                    if (lane == 0) base = atomicAdd(pa.tap_count, (uint32_t)__popcll(tb2));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (tapped) {
+                        float *t = pa.tap + base + wave_rank(tb2);
+                        const size_t cap = pa.tap_cap;
+                        t[0 * cap] = o.x; t[1 * cap] = o.y; t[2 * cap] = o.z; t[3 * cap] = d.x; t[4 * cap] = d.y; t[5 * cap] = d.z;
+                        t[6 * cap] = thr.x; t[7 * cap] = thr.y; t[8 * cap] = thr.z; t[9 * cap] = __uint_as_float(pv);
+                    }
+                }
+                onward = onward && !tapped;
+            }
             if (__any(onward)) {
                 // the stack by the walk ahead of the scattered ray (rays the kernel will not walk: the short one)
                 const GridArgs &lga = *reinterpret_cast<const GridArgs *>(ctrl + 100);

@@ -138,6 +138,14 @@ __device__ __forceinline__ bool cull_sphere(const float *bmin, const float *bmax
     return !((perp2 > lim) || (b < 0.0f && c2 > lim));
 }
 
+#ifdef PT_CULL_STATS
+static __device__ unsigned long long g_cull_stats[16];  // [8..15] typed-queue kernel: fresh groups, fresh valid lanes, box groups, box lanes, sphere groups, sphere lanes, shaded lanes, re-queued lanes
+__device__ __forceinline__ void qstat(int i, unsigned long long v) { if ((threadIdx.x & 63) == 0 && v) atomicAdd(&g_cull_stats[i], v); }
+// [0..7] lock-step kernels: [0] groups, [1] box iters, [2] box active lanes, [3] sph iters, [4] sph active lanes, [5] candidates
+// whole-path kernel with meshes (tools/meshstats.py): [0] mesh_test calls (waves) [1] lanes in them [2] BVH node visits (wave trips)
+// [3] lanes active in them [4] triangle tests (lanes)
+#endif
+
 // ------------------------------------------------------------------ MESH primitive --------------
 // Exact test of a MESH primitive: the nearest triangle by object-space t, ties to the earlier
 // triangle -- the oracle's brute-force loop -- found through the mesh's threaded BVH.  The slab tests are cull-side
@@ -156,7 +164,13 @@ __device__ __forceinline__ float mesh_test(const GeomRec *g, f3 o, f3 d, f3 &P, 
     float best = 3.0e38f;
     int win = -1, widx = 0x7FFFFFFF;
     int node = 0;
+#ifdef PT_MESH_STATS
+    { const unsigned long long act = __ballot(1); if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(act)) { atomicAdd(&g_cull_stats[0], 1ull); atomicAdd(&g_cull_stats[1], (unsigned long long)__popcll(act)); } }
+#endif
     while (node >= 0) {
+#ifdef PT_MESH_STATS
+        { const unsigned long long act = __ballot(1); if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(act)) { atomicAdd(&g_cull_stats[2], 1ull); atomicAdd(&g_cull_stats[3], (unsigned long long)__popcll(act)); } }
+#endif
         const float4 lo = *reinterpret_cast<const float4 *>(nodes[node].bmin);      // bmin.xyz, skip
         const float4 hi = *reinterpret_cast<const float4 *>(nodes[node].bmax);      // bmax.xyz, leaf
         const float bl[3] = {lo.x, lo.y, lo.z}, bh[3] = {hi.x, hi.y, hi.z};
@@ -167,6 +181,9 @@ __device__ __forceinline__ float mesh_test(const GeomRec *g, f3 o, f3 d, f3 &P, 
         if (leaf < 0) { node = node + 1; continue; }
         const int first = leaf & 0x7FFFFFF, cnt = (int)((uint32_t)leaf >> 27);
         for (int k = 0; k < cnt; ++k) {
+#ifdef PT_MESH_STATS
+            atomicAdd(&g_cull_stats[4], 1ull);
+#endif
             const float4 *tp = reinterpret_cast<const float4 *>(tris + first + k);
             const float4 a = tp[0], b = tp[1], c = tp[2];
             const float t = triangle_test(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), ro, rd);
@@ -180,11 +197,6 @@ __device__ __forceinline__ float mesh_test(const GeomRec *g, f3 o, f3 d, f3 &P, 
     return mesh_finish(inv, xf, o, ro, rd, best, mk(ngv.x, ngv.y, ngv.z), P, N);
 }
 
-#ifdef PT_CULL_STATS
-static __device__ unsigned long long g_cull_stats[16];  // [8..15] typed-queue kernel: fresh groups, fresh valid lanes, box groups, box lanes, sphere groups, sphere lanes, shaded lanes, re-queued lanes
-__device__ __forceinline__ void qstat(int i, unsigned long long v) { if ((threadIdx.x & 63) == 0 && v) atomicAdd(&g_cull_stats[i], v); }
-// [0..7] lock-step kernels: [0] groups, [1] box iters, [2] box active lanes, [3] sph iters, [4] sph active lanes, [5] candidates
-#endif
 
 template <bool GEOM_LDS>
 __device__ __forceinline__ int nearest_hit_culled(const GeomRec *lg, const GeomRec *__restrict__ gg, int G, f3 o, f3 d,
@@ -619,11 +631,16 @@ struct QTables {
 //     holds more than 63 + 2 x 64 rays), else a group of camera rays, else whatever is left.
 // No barrier, no inter-wave traffic, no pool; per-level live counts through one LDS atomic per group.  Results: the same image, live
 // counts and emitter hits as every other kernel (the rays of a bounce are a set, not a sequence).
+#ifndef PT_P_SPLIT
+#define PT_P_SPLIT 0                     // 1 (experiment, measured 29 % slower: DESIGN.md appendix): a queue record keeps what the exact test reads
+#endif                                   //    (origin, direction, mask, candidate | level: 8 dwords) in LDS and parks throughput + pixel word in the wave's
+                                         //    arena in global memory: 168 records per wave at six blocks per CU where 12-dword records give 138 at five
 #ifndef PT_P_CAP
-#define PT_P_CAP 138                     // records per wave (12 dwords each): 5 blocks = 20 waves per CU; 4 blocks with more records and 6 with fewer measured slower
+#define PT_P_CAP (PT_P_SPLIT ? 168 : 138)  // records per wave
 #endif
 constexpr uint32_t kPCap = PT_P_CAP;
-constexpr uint32_t kPFields = 12;        // ox oy oz dx dy dz tx ty tz pixelword mask candidate|level<<8
+constexpr uint32_t kPFields = PT_P_SPLIT ? 8 : 12;   // ox oy oz dx dy dz [tx ty tz pixelword] mask candidate|level<<8
+constexpr uint32_t kPParked = PT_P_SPLIT ? 4 : 0;    // tx ty tz pixelword per record, in the arena behind the wave's stack
 #ifndef PT_STACK_SLOTS
 #define PT_STACK_SLOTS 256               // a smaller value is a test build: it provokes the overflow guard (tests/test_gpu_round3.py)
 #endif
@@ -631,6 +648,12 @@ constexpr uint32_t kStack = PT_STACK_SLOTS;   // rays on a wave's stack (bound: 
 constexpr uint32_t kSFields = 11;        // ox oy oz dx dy dz tx ty tz pixelword level
 constexpr uint32_t kTicketCtrs = 16, kTicketStride = 64;
 constexpr uint32_t kJobMax = 128;        // camera rays per job: about 1/48 of a wave's share of the launch, 64 .. kJobMax
+
+// Scope of the fences between a wave's stores to its OWN arena (stack of survivors, parked words) and its later loads of them.
+// "workgroup" makes the wave wait until the stores have landed (s_waitcnt vmcnt(0)) before it loads.
+#ifndef PT_SELF_SCOPE
+#define PT_SELF_SCOPE "workgroup"
+#endif
 
 struct PathArgs {
     float *arena;                    // [waves][kSFields][kStack]
@@ -645,6 +668,11 @@ struct PathArgs {
     uint32_t *error;
     uint32_t turn_limit;             // scheduling turns a wave may take before it gives up with error 3 (2^24: never reached; tests lower it)
     float qscale, slack_max;         // k_path_w: candidate keys carry floor(entry distance * qscale); largest GeomRec::slack of the scene
+    // parity hook (pt_debug_trace_pool with ordering = 2): rays that survive bounce tap_level - 1 are written here (10 fields, SoA,
+    // stride tap_cap, in the order the waves meet them; the host sorts them by pixel) instead of going on to their next bounce
+    float *tap;
+    uint32_t *tap_count;
+    uint32_t tap_level, tap_cap;     // tap_level 0: off (every render)
 };
 constexpr uint32_t kWPayload = 15;   // k_path_w: floats per payload record in global memory (throughput, pixel word, level, best hit's P and N, direction, hit | face)
 
@@ -804,9 +832,10 @@ hipError_t queue_setup(bool mesh, uint32_t lds_bytes, int *blocks_per_cu);
 void queue_launch(bool mesh, bool last, bool gen, int grid, uint32_t lds_bytes, hipStream_t stream, const SegArgs &a,
                   const GeomRec *geoms, const MatRec *mats, const QTables &qt);
 
-hipError_t path_setup(bool mesh, uint32_t lds_bytes, int *blocks_per_cu);
-void path_launch(bool mesh, int grid, uint32_t lds_bytes, hipStream_t stream, const SegArgs &a, const PathArgs &pa,
+hipError_t path_setup(bool mesh, bool nee, uint32_t lds_bytes, int *blocks_per_cu);
+void path_launch(bool mesh, bool nee, int grid, uint32_t lds_bytes, hipStream_t stream, const SegArgs &a, const PathArgs &pa,
                  const GeomRec *geoms, const MatRec *mats, const QTables &qt);
+constexpr uint32_t kNeeExtraFields = 9;  // k_path_q<NEE>: words a stack / parked record holds beyond the common ones
 
 // k_path_w (pt_k_wide.hip): `variant` picks the block shape; the layout says what it needs
 struct WideLayout { uint32_t waves_per_block, slots_per_wave, payload_per_wave, stack_slots, lds_bytes; };

@@ -155,8 +155,15 @@ def test_no_emitters_means_no_contribution():
     ("cornell_mirror", 6, 5, dict(batch=2, chunk_rays=100)),
     ("cornell_glass_4k", 12, 3, dict(camera_mode=1, antialias=1, aperture=0.25, focal_distance=12.0)),
     ("random256", 8, 2, dict()),
-    ("sampleScene", 2, 3, dict(ordering=1)),                           # ordering is ignored, not an error
+    ("sampleScene", 2, 3, dict(ordering=1)),                           # ordering 1 is ignored, not an error
+    # ordering = 2 on <= 32 primitives: whole paths in one launch, the shadow rays as records of the typed queues (k_path_q<NEE>)
     ("sampleScene", 3, 2, dict(ordering=2)),
+    ("sampleScene", 8, 5, dict(ordering=2)),
+    ("cornell_mirror", 8, 4, dict(ordering=2, batch=1)),
+    ("cornell_mirror", 6, 5, dict(ordering=2, batch=2, chunk_rays=128)),
+    ("cornell_mirror", 8, 3, dict(ordering=2, streams=2)),
+    ("cornell_glass_4k", 12, 3, dict(ordering=2, camera_mode=1, antialias=1, aperture=0.25, focal_distance=12.0)),
+    ("random256", 8, 2, dict(ordering=2)),                             # more than 32 primitives: the per-bounce kernels, as before
 ])
 def test_gpu_image_and_live_counts_match_oracle(pt, name, depth, iters, kw):
     sc = orc.load_golden_scene(name).with_resolution(160, 120)
@@ -172,9 +179,10 @@ def test_gpu_image_and_live_counts_match_oracle(pt, name, depth, iters, kw):
 
 
 @pytest.mark.gpu
-def test_gpu_sphere_emitter_and_host_image_round_trip(pt):
+@pytest.mark.parametrize("ordering", [0, 2])
+def test_gpu_sphere_emitter_and_host_image_round_trip(pt, ordering):
     sc = _sphere_light_scene(96, 64)
-    tr = make_tracer(sc, depth=5, direct_light=1)
+    tr = make_tracer(sc, depth=5, direct_light=1, ordering=ordering)
     start = np.random.default_rng(3).random((64, 96, 3)).astype(np.float32)
     tr.set_image(start)
     tr.render(1, 2)
@@ -203,12 +211,13 @@ def test_gpu_pool_and_flag_bit_exact(pt, bounces):
 
 
 @pytest.mark.gpu
-def test_gpu_row_shards_sum_to_the_full_frame(pt):
+@pytest.mark.parametrize("ordering", [0, 2])
+def test_gpu_row_shards_sum_to_the_full_frame(pt, ordering):
     sc = orc.load_golden_scene("sampleScene").with_resolution(128, 96)
     want, _ = orc.render(sc, oracle_config(6, direct_light=1), 1, 3)
     total = np.zeros_like(want)
     for r in range(3):
-        tr = make_tracer(sc, depth=6, direct_light=1, row_offset=r, row_stride=3)
+        tr = make_tracer(sc, depth=6, direct_light=1, row_offset=r, row_stride=3, ordering=ordering)
         tr.set_image(None)
         tr.render(1, 3)
         part = tr.image()
@@ -230,10 +239,11 @@ def test_gpu_rejects_unsupported_combinations(pt):
 
 
 @pytest.mark.gpu
-def test_gpu_full_size_1080p_one_iteration(pt):
+@pytest.mark.parametrize("ordering", [0, 2])
+def test_gpu_full_size_1080p_one_iteration(pt, ordering):
     """BASELINE configs[2] geometry at full size with shadow rays: image and live counts equal the oracle."""
     sc = orc.load_golden_scene("cornell_mirror")
-    tr = make_tracer(sc, depth=8, direct_light=1)
+    tr = make_tracer(sc, depth=8, direct_light=1, ordering=ordering)
     tr.set_image(None)
     tr.render(1, 1)
     want, live = orc.render(sc, oracle_config(8, direct_light=1), 1, 1)

@@ -156,3 +156,25 @@ def test_mesh_bench_workloads_render_what_the_oracle_renders(pt, workload):
         assert [st.live[k] for k in range(7)] == [int(v) for v in live], kw
         assert np.array_equal(tr.image(), want), kw
         tr.close()
+
+
+@pytest.mark.parametrize("name,w,h,bounces", [("cornell_mirror", 200, 150, 1), ("cornell_mirror", 200, 150, 4), ("cornell_mirror", 200, 150, 7),
+                                              ("cornell_glass_4k", 160, 90, 3), ("random256", 160, 120, 1), ("random256", 160, 120, 3), ("random256", 160, 120, 6)])
+def test_whole_path_kernels_ray_records_match_the_oracle_pool(pt, name, w, h, bounces):
+    """with ordering = 2 the pool hook probes the WHOLE-PATH kernels themselves -- the rays that survive
+    bounce k - 1 leave k_path_q / k_path_w through a tap (in whatever order the waves meet them), the host sorts them by pixel --
+    so origin, direction, throughput and pixel word of every live ray are compared with the oracle's pool, not only images."""
+    sc = orc.load_golden_scene(name).with_resolution(w, h)
+    tr = make_tracer(sc, depth=8, ordering=2)
+    n, arrs, pix = tr.trace_pool(2, bounces)
+    on, oarrs, opix = orc.trace_pool(sc, oracle_config(8), 2, bounces)
+    assert n == on and n > 0
+    assert np.array_equal(pix, opix)
+    for a, b in zip(arrs, oarrs):
+        assert np.array_equal(a, b)
+    # the hook leaves image and statistics untouched, and the stable kernels' pool is the same
+    tr.set_image(None); tr.render(1, 2)
+    want, live = orc.render(sc, oracle_config(8), 1, 2)
+    assert np.array_equal(tr.image(), want)
+    assert [int(tr.stats().live[k]) for k in range(9)] == [int(v) for v in live]
+    tr.close()
