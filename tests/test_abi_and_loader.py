@@ -54,12 +54,12 @@ def test_options_retired_in_abi7_are_refused_before_any_device_is_touched(pkg):
     """geometry_path=1, the look-back scan (compaction=1) and merge_floor were measured losers and left the launch
     matrix in ABI 7: the fields stay (layout), non-zero values are an argument error -- with or without a GPU."""
     import ctypes as C
-    for kw in (dict(geometry_path=1), dict(compaction=1), dict(merge_floor=4), dict(path_static_eighths=9), dict(cluster_size=99)):
+    for kw in (dict(geometry_path=1), dict(compaction=1), dict(merge_floor=4), dict(path_static_eighths=9), dict(cluster_size=99), dict(grid_density=65), dict(grid_density=-1)):
         cfg = pkg.default_config(**kw)
         h = C.c_void_p()
         assert pkg.lib().pt_create(C.byref(cfg), C.byref(h)) == -3, kw          # PT_ERR_ARGUMENT
         assert not h.value
-    assert pkg.default_config().path_static_eighths == 4
+    assert pkg.default_config().path_static_eighths == 4 and pkg.default_config().grid_density == 0       # (ABI 8: 0 = four cells per small primitive)
 
 
 def test_library_reads_no_environment_switches():

@@ -146,6 +146,9 @@ def test_grid_of_the_bench_scene_is_small_and_cheap(pt):
     assert info["cells"] <= 2048 and info["lds_bytes"] <= 10 * 1024
     assert sets.sum(1).mean() < 12.0
     assert info["mean_walk"] <= 9
+    # the walk-length estimate the survivors are sorted by (span of the ray inside the grid's box in cell units): within two cells
+    assert info["length_estimate_worst"] <= 2 and info["length_estimate_mean_error_x100"] < 80
+    assert 2 <= info["bin1"] < info["bin2"]
 
 
 def test_grid_when_everything_is_big_or_flat(pt):

@@ -27,7 +27,7 @@ def short(name):
         if len(flags) > 3 and flags[3]:
             tag += ",gen"
         return tag + ">"
-    for k in ("k_path_q", "k_generate", "k_flat", "k_display"):
+    for k in ("k_path_q", "k_path_w", "k_fold", "k_generate", "k_flat", "k_display"):
         if k in name:
             return k
     return name[:60]

@@ -27,7 +27,7 @@ rec[workload] = {
     "hbm_bytes_per_step": round((2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 / steps),
     "hbm_bytes_per_step_uncorrected": round((tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 / steps),
     "steps_profiled": steps, "dispatches": dispatches, "profile": tag, "kernel_source_id": kernel_source_id(),
-    "ordering": 2 if workload != "c4" else None,      # bench.py --ordering the profile was taken with (None: the workload runs the stable kernels whatever it is)
+    "ordering": 2,                                   # bench.py --ordering the profile was taken with
     "valu_wave_instructions_per_step": round(tot["SQ_INSTS_VALU"] / steps),
     "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of the bench.py command in tools/profile.sh (%s, bench "
            "defaults); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch (gfx950 FETCH_SIZE counts 64 B per 128-B request on wide "
