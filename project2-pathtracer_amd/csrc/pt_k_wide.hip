@@ -66,8 +66,12 @@ namespace {
 // slot fields (SoA, stride R dwords, wave-private LDS)
 enum : uint32_t { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_L0, F_L1, F_L2, F_L3, F_META, F_BEST, F_COUNT };
 // payload fields (SoA, stride R floats, global memory, per wave)
-enum : uint32_t { P_TX = 0, P_TY, P_TZ, P_PV, P_LEVEL, P_PX, P_PY, P_PZ, P_NX, P_NY, P_NZ, P_DX, P_DY, P_DZ, P_HIT };
-static_assert(P_HIT + 1 == kWPayload, "payload record");
+// payload record (global memory, per wave): ONE 64-byte line per ray, four 16-byte quarters -- a lane of a TEST or SHADE group
+// holds some ray of the wave, so field-major arrays would cost it a different cache line per field:
+//   Q_THR throughput.xyz, pixel word | Q_DIR level, direction.xyz | Q_HIT best hit's point.xyz, hit | (face + 1) << 8 | Q_NRM its normal.xyz (spheres), -
+enum : uint32_t { Q_THR = 0, Q_DIR = 1, Q_HIT = 2, Q_NRM = 3 };
+static_assert(kWPayload == 16, "payload record: one 64-byte line");
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 static_assert(kWalkBins == 3, "the survivors' stacks are written out as sp0, sp1, sp2");
 static_assert(100 * 4 + sizeof(GridArgs) <= kCtrlBytes, "the parked GridArgs must fit behind the survivors' counters in the control block");
 
@@ -158,8 +162,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
     const uint32_t poff = woff + kWalkBins * kSFields * STK;
     auto ring_ld = [&](uint32_t off, uint32_t f) -> float { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off * 4u, f * STK * 4u, 0)); };
     auto ring_st = [&](uint32_t off, uint32_t f, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, off * 4u, f * STK * 4u, 0); };
-    auto pay_ld = [&](uint32_t pid, uint32_t f) -> float { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (poff + pid) * 4u, f * (uint32_t)NP * 4u, 0)); };
-    auto pay_st = [&](uint32_t pid, uint32_t f, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, (poff + pid) * 4u, f * (uint32_t)NP * 4u, 0); };
+    auto pay_ld = [&](uint32_t pid, uint32_t q) -> u32x4 { return __builtin_amdgcn_raw_buffer_load_b128(rs, (poff + pid * kWPayload) * 4u, q * 16u, 0); };
+    auto pay_st = [&](uint32_t pid, uint32_t q, float a, float b, float c, float d) {
+        u32x4 v; v.x = __float_as_uint(a); v.y = __float_as_uint(b); v.z = __float_as_uint(c); v.w = __float_as_uint(d);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, (poff + pid * kWPayload) * 4u, q * 16u, 0);
+    };
 
     uint32_t *bank = a.bank ? a.sync->counts_b : a.sync->counts;
     if (blockIdx.x == 0 && threadIdx.x < 72) {
@@ -309,9 +316,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
                 wf[F_DX * R + sid] = d.x; wf[F_DY * R + sid] = d.y; wf[F_DZ * R + sid] = d.z;
                 wl[F_L0 * R + sid] = 0xFFFFFFFFu; wl[F_L1 * R + sid] = 0xFFFFFFFFu; wl[F_L2 * R + sid] = 0xFFFFFFFFu; wl[F_L3 * R + sid] = 0xFFFFFFFFu;
                 // what only the shading needs waits in the ray's payload record: throughput, pixel word, level, direction
-                pay_st(pid, P_TX, thr.x); pay_st(pid, P_TY, thr.y); pay_st(pid, P_TZ, thr.z);
-                pay_st(pid, P_PV, __uint_as_float(pv)); pay_st(pid, P_LEVEL, __uint_as_float(level));
-                pay_st(pid, P_DX, d.x); pay_st(pid, P_DY, d.y); pay_st(pid, P_DZ, d.z);
+                pay_st(pid, Q_THR, thr.x, thr.y, thr.z, __uint_as_float(pv));
+                pay_st(pid, Q_DIR, __uint_as_float(level), d.x, d.y, d.z);
             }
             nfree -= nv; npfree -= nv;
             const CullRay cr = make_cull_ray(o, d);
@@ -575,8 +581,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
             }
             // the new best hit's point and normal wait in the payload record (an earlier winner's stay there otherwise)
             if (won) {
-                pay_st(pid, P_PX, P.x); pay_st(pid, P_PY, P.y); pay_st(pid, P_PZ, P.z);
-                if (!isb) { pay_st(pid, P_NX, N.x); pay_st(pid, P_NY, N.y); pay_st(pid, P_NZ, N.z); }
+                pay_st(pid, Q_HIT, P.x, P.y, P.z, __uint_as_float(hit | ((uint32_t)(face + 1) << 8)));
+                if (!isb) pay_st(pid, Q_NRM, N.x, N.y, N.z, 0.0f);
             }
             // the next candidate that could still win or tie: key distance not beyond the best hit (conservative: one step of slack)
             PT_PHASE(7);
@@ -602,7 +608,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
             const bool toshade = done && has_hit;
             bool shb = false;
             if (toshade) {
-                pay_st(pid, P_HIT, __uint_as_float(hit | ((uint32_t)(face + 1) << 8)));
                 shb = lg[hit].type == 1;
             }
             PT_WSTAT(20, __popcll(__ballot(toshade))); PT_WSTAT(21, __popcll(__ballot(done)));
@@ -647,13 +652,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
             f3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(0, 0, 0), P = mk(0, 0, 0), N = mk(0, 0, 0);
             if (valid) {
                 pid = shstack[hbx ? have - cnt + lane : (uint32_t)NP - 1u - (have - cnt + lane)];
-                thr = mk(pay_ld(pid, P_TX), pay_ld(pid, P_TY), pay_ld(pid, P_TZ));
-                pv = __float_as_uint(pay_ld(pid, P_PV));
-                level = __float_as_uint(pay_ld(pid, P_LEVEL));
-                d = mk(pay_ld(pid, P_DX), pay_ld(pid, P_DY), pay_ld(pid, P_DZ));
-                P = mk(pay_ld(pid, P_PX), pay_ld(pid, P_PY), pay_ld(pid, P_PZ));
-                hf = __float_as_uint(pay_ld(pid, P_HIT));
-                if (!hbx) N = mk(pay_ld(pid, P_NX), pay_ld(pid, P_NY), pay_ld(pid, P_NZ));
+                const u32x4 qa = pay_ld(pid, Q_THR), qb = pay_ld(pid, Q_DIR), qc = pay_ld(pid, Q_HIT);
+                thr = mk(__uint_as_float(qa.x), __uint_as_float(qa.y), __uint_as_float(qa.z)); pv = qa.w;
+                level = qb.x; d = mk(__uint_as_float(qb.y), __uint_as_float(qb.z), __uint_as_float(qb.w));
+                P = mk(__uint_as_float(qc.x), __uint_as_float(qc.y), __uint_as_float(qc.z)); hf = qc.w;
+                if (!hbx) { const u32x4 qd = pay_ld(pid, Q_NRM); N = mk(__uint_as_float(qd.x), __uint_as_float(qd.y), __uint_as_float(qd.z)); }
             }
             const uint32_t hit = hf & 0xFFu;
             const int face = (int)((hf >> 8) & 7u) - 1;

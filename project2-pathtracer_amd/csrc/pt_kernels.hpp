@@ -674,7 +674,7 @@ struct PathArgs {
     uint32_t *tap_count;
     uint32_t tap_level, tap_cap;     // tap_level 0: off (every render)
 };
-constexpr uint32_t kWPayload = 15;   // k_path_w: floats per payload record in global memory (throughput, pixel word, level, best hit's P and N, direction, hit | face)
+constexpr uint32_t kWPayload = 16;   // k_path_w: floats per payload record in global memory: one 64-byte line per ray (layout: pt_k_wide.hip)
 
 // k_path_w's spatial index: a uniform grid over the SMALL analytic primitives (host: build_grid, pt_api.hip).  A ray
 // walks the cells it crosses (3D-DDA) and only the primitives listed there have their own bounds tested; primitives
