@@ -770,11 +770,12 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     }
     // MESH primitives with registered data (the others are skipped like the reference's empty branch)
     std::vector<const pt_context::HostMesh *> mesh_of(G, nullptr);
-    bool have_mesh = false;
+    bool have_mesh = false, big_mesh = false;              // big: beyond what a (ray, triangle) pair of k_path_q<MESH> indexes
     for (const pt_context::HostMesh &hm : c->meshes) {
         if (hm.geom_index >= G || geoms[hm.geom_index].type != 2) { pth::set_error("pt_upload_scene: mesh registered for geom %d, which is not a MESH of this scene", hm.geom_index); return PT_ERR_ARGUMENT; }
         mesh_of[hm.geom_index] = &hm;
         have_mesh = true;
+        if (hm.idx.size() / 3 >= (size_t)kMeshPairTris) big_mesh = true;
         if (c->cfg.direct_light != 0 && mats[geoms[hm.geom_index].materialid].emittance > 0.0f) { pth::set_error("pt_upload_scene: direct_light does not sample emitting meshes (geom %d)", hm.geom_index); return PT_ERR_ARGUMENT; }
     }
     const int stride = c->cfg.row_stride, offset = c->cfg.row_offset;
@@ -1023,16 +1024,17 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         HIPCHK(hipMemcpy(c->d_cull, cr.data(), cr.size() * sizeof(CullRec), hipMemcpyHostToDevice));
     }
     // ordering = 2: whole paths in one launch -- a persistent grid of its own and the waves' level rings
-    c->pathq = (c->queue && c->cfg.ordering == 2 && !c->nee) || c->pathq_nee;
+    c->pathq = (c->queue && c->cfg.ordering == 2 && !c->nee && !big_mesh) || c->pathq_nee;       // (a mesh of 2^24 triangles or more: per-bounce kernels)
     if (c->pathq) {
-        c->lds_path = p_lds_bytes(G, M);
+        c->lds_path = c->queue_mesh ? p_mesh_lds_bytes(G, M) : p_lds_bytes(G, M);
         int occ = 0;
         HIPCHK(path_setup(c->queue_mesh, c->pathq_nee, c->lds_path, &occ));
         if (c->cfg.blocks_per_cu > 0) occ = c->cfg.blocks_per_cu;
         c->grid_path = c->n_cu * occ;
         c->path_waves = (uint32_t)kWaves;
         const size_t extra = c->pathq_nee ? kNeeExtraFields : 0;
-        c->arena_bytes = (size_t)c->grid_path * kWaves * (((size_t)kSFields + extra) * kStack + ((size_t)kPParked + extra) * kPCap) * sizeof(float);
+        c->arena_bytes = (size_t)c->grid_path * kWaves * (((size_t)kSFields + extra) * kStack + ((size_t)kPParked + extra) * kPCap +
+                                                           (c->queue_mesh ? (size_t)kMFields * kMStack : 0)) * sizeof(float);
         HIPCHK(hipMalloc(&c->d_arena, c->arena_bytes));
         HIPCHK(hipMalloc(&c->d_tickets, (size_t)kTicketCtrs * kTicketStride * sizeof(uint32_t)));
     }

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : NEE ? 5 : 6) void k_path_q(SegAr
     float *q = reinterpret_cast<float *>(smem + p_queue_offset(a.G, a.M)) + (size_t)wave * kPCap * kPFields;
     // the wave's arena: its stack (field f of slot s at woff + f * kStack + s), then what the queue records park (field f of record r
     // at poff + f * kPCap + r)
-    const uint32_t wave_floats = SF * kStack + PF * kPCap;
+    const uint32_t wave_floats = SF * kStack + PF * kPCap + (MESH ? kMFields * kMStack : 0u);
     const bool ub = pa.arena_bytes != 0u;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pa.arena, 0, pa.arena_bytes, 0x00020000);
     const uint32_t woff = wslot * wave_floats;             // in floats (buffer path: arena below 4 GiB)
@@ -70,6 +70,44 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : NEE ? 5 : 6) void k_path_q(SegAr
     auto park_st = [&](uint32_t pos, uint32_t f, float v) {
         if (ub) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, (poff + pos) * 4u, f * kPCap * 4u, 0);
         else pa.arena[(size_t)poff + pos + f * kPCap] = v;
+    };
+
+    // MESH: the third typed stack (pt_kernels.hpp, kMStack) and the scratch of the mesh stages
+    const uint32_t moff = poff + PF * kPCap;
+    auto mesh_ld = [&](uint32_t off, uint32_t f) -> float {
+        return ub ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off * 4u, f * kMStack * 4u, 0)) : pa.arena[(size_t)off + f * kMStack];
+    };
+    auto mesh_st = [&](uint32_t off, uint32_t f, float v) {
+        if (ub) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, off * 4u, f * kMStack * 4u, 0);
+        else pa.arena[(size_t)off + f * kMStack] = v;
+    };
+    unsigned long long *mkey = reinterpret_cast<unsigned long long *>(smem + p_mesh_offset(a.G, a.M) + (MESH ? wave * kMScratchBytes : 0u));
+    uint32_t *mposn = reinterpret_cast<uint32_t *>(mkey + 64);
+    uint32_t *mpair = mposn + 64;
+    constexpr unsigned long long kMeshNoHit = (0x7F61B1E6ull << 32) | 0x7FFFFFFFull;      // (3.0e38f, no triangle): mesh_test's initial best
+    uint32_t nmesh = 0u;
+    // a ray goes on the mesh stack: `c` lanes, everything a later MESH turn needs
+    auto mesh_push = [&](bool c, f3 o, f3 d, f3 thr, uint32_t pv, uint32_t mask, uint32_t jl, float best, int hit, int face, f3 P, f3 N,
+                         int node, unsigned long long key, uint32_t mpos) {
+        const u64 b = __ballot(c);
+        if (b == 0ull) return;
+        const uint32_t n = (uint32_t)__popcll(b);
+        if (nmesh + n > kMStack) { if (lane == 0) *pa.error = 2u; return; }               // never: see kMStack
+        if (c) {
+            const uint32_t off = moff + nmesh + wave_rank(b);
+            mesh_st(off, 0, o.x); mesh_st(off, 1, o.y); mesh_st(off, 2, o.z);
+            mesh_st(off, 3, d.x); mesh_st(off, 4, d.y); mesh_st(off, 5, d.z);
+            mesh_st(off, 6, thr.x); mesh_st(off, 7, thr.y); mesh_st(off, 8, thr.z);
+            mesh_st(off, 9, __uint_as_float(pv)); mesh_st(off, 10, __uint_as_float(mask)); mesh_st(off, 11, __uint_as_float(jl));
+            mesh_st(off, 12, best); mesh_st(off, 13, __uint_as_float((uint32_t)(hit + 1) | ((uint32_t)(face + 1) << 8)));
+            if (hit >= 0) {
+                mesh_st(off, 14, P.x); mesh_st(off, 15, P.y); mesh_st(off, 16, P.z);
+                mesh_st(off, 17, N.x); mesh_st(off, 18, N.y); mesh_st(off, 19, N.z);
+            }
+            mesh_st(off, 20, __int_as_float(node)); mesh_st(off, 21, __uint_as_float((uint32_t)key)); mesh_st(off, 22, __uint_as_float((uint32_t)(key >> 32)));
+            mesh_st(off, 23, __uint_as_float(mpos));
+        }
+        nmesh += n;
     };
 
     // radiance -> the path's pixel: of the frame, or of its iteration's accumulator plane (owned rows only)
@@ -122,8 +160,10 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : NEE ? 5 : 6) void k_path_q(SegAr
         nbox = __builtin_amdgcn_readfirstlane(nbox); nsph = __builtin_amdgcn_readfirstlane(nsph); sp = __builtin_amdgcn_readfirstlane(sp);
         jobpos = __builtin_amdgcn_readfirstlane(jobpos); jobend = __builtin_amdgcn_readfirstlane(jobend);
         round = __builtin_amdgcn_readfirstlane(round); ctr = __builtin_amdgcn_readfirstlane(ctr); dry = __builtin_amdgcn_readfirstlane(dry);
-        int act;
-        if (nbox >= 64u) act = 1;
+        int act;                                           // 0 FRESH from the stack, 3 FRESH camera rays, 1 TEST cubes, 2 TEST spheres, 4 MESH
+        if constexpr (MESH) nmesh = __builtin_amdgcn_readfirstlane(nmesh);
+        if (MESH && nmesh >= kMeshTurn) act = 4;
+        else if (nbox >= 64u) act = 1;
         else if (nsph >= 64u) act = 2;
         else if (nbox + nsph <= kPCap - 64u) {
             if (sp >= 64u) act = 0;
@@ -148,7 +188,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : NEE ? 5 : 6) void k_path_q(SegAr
                 }
                 if (jobpos < jobend) act = 3;
                 else if (sp) act = 0;
-                else if (nbox + nsph) act = nbox >= nsph ? 1 : 2;
+                else if (nbox + nsph + nmesh) act = (nmesh > nbox && nmesh > nsph) ? 4 : nbox >= nsph ? 1 : 2;
                 else break;
             }
         } else act = nbox >= nsph ? 1 : 2;
@@ -220,14 +260,18 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : NEE ? 5 : 6) void k_path_q(SegAr
             const bool push = mask != 0u;
 #ifdef PT_CULL_STATS
             qstat(8, 1ull); qstat(9, (unsigned long long)__popcll(__ballot(valid)));
+#ifndef PT_MESH_STATS
             atomicAdd(&g_cull_stats[5], (unsigned long long)__popc(mask));
             if (act == 3) qstat(6, 1ull);
 #endif
+#endif
             mask &= ~(1u << next_j);
             const bool tobox = push && ((boxbits >> next_j) & 1u);
-            const u64 bb = __ballot(tobox), sb = __ballot(push && !tobox);
+            const bool tomesh = MESH && push && ((meshbits >> next_j) & 1u);
+            if constexpr (MESH) mesh_push(tomesh, o, d, thr, pv, mask, next_j | (level << 8), kInf, -1, -1, mk(0, 0, 0), mk(0, 0, 0), 0, kMeshNoHit, 0u);
+            const u64 bb = __ballot(tobox), sb = __ballot(push && !tobox && !tomesh);
             if (bb | sb) {
-                if (push) {
+                if (push && !tomesh) {
                     const uint32_t pos = tobox ? nbox + wave_rank(bb) : kPCap - 1u - (nsph + wave_rank(sb));
                     float *r = q + pos;
                     r[0 * kPCap] = o.x; r[1 * kPCap] = o.y; r[2 * kPCap] = o.z;
@@ -276,21 +320,178 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : NEE ? 5 : 6) void k_path_q(SegAr
             continue;
         }
 
-        // -------------------------------------------------------------------- TEST (one type per group, any levels)
+        // -------------------------------------------------------------------- TEST (one type per group, any levels) / MESH
         const bool isb = act == 1;
-        const uint32_t have = isb ? nbox : nsph;
-        const uint32_t cnt = have < 64u ? have : 64u;
-        const bool valid = lane < cnt;
-        const uint32_t pos = isb ? (have - cnt + lane) : (kPCap - 1u - (have - cnt + lane));
-        if (isb) nbox -= cnt; else nsph -= cnt;
-#ifdef PT_CULL_STATS
-        qstat(isb ? 10 : 12, 1ull); qstat(isb ? 11 : 13, (unsigned long long)cnt);
-#endif
+        bool valid;
         f3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(0, 0, 0);
         uint32_t pv = 0u, mask = 0u, level = 0u;
         f3 acc = mk(0, 0, 0), nd = mk(0, 0, 0);                               // NEE only
         float cos_s = 0.0f, invpdf = 0.0f, dist2 = 0.0f;
         int j = 0;
+        float best = kInf;
+        int hit = -1, face = -1;
+        f3 P = mk(0, 0, 0), N = mk(0, 0, 0);
+        uint32_t lw = 0u;                                                     // NEE: the level word (level | shadow << 8 | count-emission << 9 | light << 10)
+        if (MESH && act == 4) {
+            if constexpr (MESH) {
+                // ------------------------------------------------------------ MESH: the top 64 rays of the mesh stack
+                const uint32_t cnt = nmesh < 64u ? nmesh : 64u;
+                valid = lane < cnt;
+                nmesh -= cnt;
+                const uint32_t off = moff + nmesh + lane;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, PT_SELF_SCOPE);        // the wave's own stack stores have landed (vmcnt 0) ...
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, PT_SELF_SCOPE);        // ... before they are read back through the same L1
+                int node = -1;
+                unsigned long long key = kMeshNoHit;
+                uint32_t mpos = 0u, jl = 0u;
+                if (valid) {                                                  // what the traversal needs; the rest of the record after it
+                    o = mk(mesh_ld(off, 0), mesh_ld(off, 1), mesh_ld(off, 2));
+                    d = mk(mesh_ld(off, 3), mesh_ld(off, 4), mesh_ld(off, 5));
+                    jl = __float_as_uint(mesh_ld(off, 11));
+                    node = __float_as_int(mesh_ld(off, 20));
+                    key = (unsigned long long)__float_as_uint(mesh_ld(off, 21)) | ((unsigned long long)__float_as_uint(mesh_ld(off, 22)) << 32);
+                    mpos = __float_as_uint(mesh_ld(off, 23));
+                }
+                j = (int)(jl & 0xFFu);
+                level = jl >> 8;
+                const GeomRec *gr = lg + j;
+                const unsigned long long mbase = ((unsigned long long)__float_as_uint(gr->bmax[3]) << 32) | (unsigned long long)__float_as_uint(gr->bmin[3]);
+                const MeshNode *nodes = reinterpret_cast<const MeshNode *>(mbase);
+                const unsigned long long tbase = mbase + (unsigned long long)(uint32_t)gr->inside_hits;
+                const f3 ro = mul_point(gr->inv, o);                          // (mesh_test's own first lines)
+                const f3 rd = normalize(mul_vector(gr->inv, d));
+                const CullRay cr = make_cull_ray(ro, rd);
+                mkey[lane] = key;
+                mposn[lane] = mpos;
+                uint32_t npairs = 0u;
+                const bool more = nmesh >= 32u;                               // other rays wait: a thin WALK gives way to them
+#ifdef PT_MESH_STATS
+                if (lane == 0) { atomicAdd(&g_cull_stats[0], 1ull); atomicAdd(&g_cull_stats[1], (unsigned long long)cnt); }
+#endif
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (;;) {
+                    const u64 wb = __ballot(node >= 0);
+                    const uint32_t nw = (uint32_t)__popcll(wb);
+                    int op;                                                   // 0 WALK, 1 TRI
+                    if (npairs >= 64u) op = 1;
+                    else if (nw == 0u || (more && nw < kMeshMinWalk)) { if (npairs) op = 1; else break; }
+                    else op = 0;
+                    if (op == 0) {
+                        // -------------------------------------------------------- WALK: lane = ray, one node of its mesh's threaded BVH
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef PT_MESH_STATS
+                        if (lane == 0) { atomicAdd(&g_cull_stats[2], 1ull); atomicAdd(&g_cull_stats[3], (unsigned long long)nw); }
+#endif
+                        bool leafhit = false;
+                        uint32_t e = 0u;
+                        if (node >= 0) {
+                            const float bt = __uint_as_float((uint32_t)(mkey[lane] >> 32));      // the ray's best triangle so far
+                            const float4 lo = *reinterpret_cast<const float4 *>(nodes[node].bmin);      // bmin.xyz, skip
+                            const float4 hi = *reinterpret_cast<const float4 *>(nodes[node].bmax);      // bmax.xyz, leaf
+                            const float bl[3] = {lo.x, lo.y, lo.z}, bh[3] = {hi.x, hi.y, hi.z};
+                            float tn;
+                            const bool in = cull_box(bl, bh, cr, tn) && !(tn > bt);
+                            const int skip = __float_as_int(lo.w), leaf = __float_as_int(hi.w);
+                            if (!in) node = skip;
+                            else if (leaf < 0) node = node + 1;
+                            else {
+                                leafhit = true;
+                                e = lane | ((((uint32_t)leaf >> 27) - 1u) << 6) | (((uint32_t)leaf & 0xFFFFFFu) << 8);
+                                node = skip;
+                            }
+                        }
+                        const u64 lb = __ballot(leafhit);
+                        if (leafhit) mpair[npairs + wave_rank(lb)] = e;
+                        npairs += (uint32_t)__popcll(lb);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    } else {
+                        // -------------------------------------------------------- TRI: lane = one (ray, triangle) pair; an entry with triangles
+                        // left in its leaf returns for the next one
+                        const uint32_t n = npairs < 64u ? npairs : 64u;
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        const bool tv = lane < n;
+                        uint32_t e = 0u;
+                        if (tv) e = mpair[npairs - n + lane];
+                        npairs -= n;
+                        const uint32_t r = e & 63u, rem = (e >> 6) & 3u, tri = e >> 8;
+                        const int ra = (int)(r << 2);
+                        const f3 pro = mk(__int_as_float(__builtin_amdgcn_ds_bpermute(ra, __float_as_int(ro.x))),
+                                          __int_as_float(__builtin_amdgcn_ds_bpermute(ra, __float_as_int(ro.y))),
+                                          __int_as_float(__builtin_amdgcn_ds_bpermute(ra, __float_as_int(ro.z))));
+                        const f3 prd = mk(__int_as_float(__builtin_amdgcn_ds_bpermute(ra, __float_as_int(rd.x))),
+                                          __int_as_float(__builtin_amdgcn_ds_bpermute(ra, __float_as_int(rd.y))),
+                                          __int_as_float(__builtin_amdgcn_ds_bpermute(ra, __float_as_int(rd.z))));
+                        const unsigned long long ptb = (unsigned long long)(uint32_t)__builtin_amdgcn_ds_bpermute(ra, (int)(uint32_t)tbase) |
+                                                       ((unsigned long long)(uint32_t)__builtin_amdgcn_ds_bpermute(ra, (int)(uint32_t)(tbase >> 32)) << 32);
+#ifdef PT_MESH_STATS
+                        if (lane == 0) { atomicAdd(&g_cull_stats[4], (unsigned long long)n); atomicAdd(&g_cull_stats[5], 1ull); }
+#endif
+                        unsigned long long mykey = kMeshNoHit;
+                        bool ok = false;
+                        if (tv) {
+                            const float4 *tp = reinterpret_cast<const float4 *>(ptb + (unsigned long long)tri * sizeof(MeshTri));
+                            const float4 va = tp[0], vb = tp[1], vc = tp[2];
+                            const float t = triangle_test(mk(va.x, va.y, va.z), mk(vb.x, vb.y, vb.z), mk(vc.x, vc.y, vc.z), pro, prd);
+                            ok = t > 0.0f;
+                            mykey = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(uint32_t)__float_as_int(va.w);
+                        }
+                        __builtin_amdgcn_wave_barrier();                      // every entry is read before any is overwritten
+                        if (ok) (void)atomicMin(&mkey[r], mykey);             // (t, index in the file): nearest, ties to the earlier triangle
+                        if (ok && mkey[r] == mykey) mposn[r] = tri;           // the winner so far says where its triangle sits
+                        const bool again = tv && rem != 0u;
+                        const u64 gb = __ballot(again);
+                        if (again) mpair[npairs + wave_rank(gb)] = r | ((rem - 1u) << 6) | ((tri + 1u) << 8);
+                        npairs += (uint32_t)__popcll(gb);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                key = mkey[lane];
+                mpos = mposn[lane];
+                // the rest of the record: the best hit so far
+                uint32_t hf = 0u;
+                if (valid) {
+                    thr = mk(mesh_ld(off, 6), mesh_ld(off, 7), mesh_ld(off, 8));
+                    pv = __float_as_uint(mesh_ld(off, 9));
+                    mask = __float_as_uint(mesh_ld(off, 10));
+                    best = mesh_ld(off, 12);
+                    hf = __float_as_uint(mesh_ld(off, 13));
+                }
+                hit = (int)(hf & 0xFFu) - 1;
+                face = (int)((hf >> 8) & 0xFFu) - 1;
+                if (valid && hit >= 0) {
+                    P = mk(mesh_ld(off, 14), mesh_ld(off, 15), mesh_ld(off, 16));
+                    N = mk(mesh_ld(off, 17), mesh_ld(off, 18), mesh_ld(off, 19));
+                }
+                // an interrupted traversal goes back with its cursor (every store below follows the load of the same field)
+                const bool unf = valid && node >= 0;
+#ifdef PT_MESH_STATS
+                { const u64 ub2 = __ballot(unf); if (lane == 0) atomicAdd(&g_cull_stats[6], (unsigned long long)__popcll(ub2)); }
+#endif
+                mesh_push(unf, o, d, thr, pv, mask, jl, best, hit, face, P, N, node, key, mpos);
+                if (unf) { hit = -1; mask = 0u; }                             // (its best hit so far went with it: nothing to shade here)
+                const bool fin = valid && node < 0;
+                if (fin && key != kMeshNoHit) {
+                    const float4 ngv = reinterpret_cast<const float4 *>(tbase + (unsigned long long)mpos * sizeof(MeshTri))[3];
+                    f3 p, nn;
+                    const float depth = mesh_finish(gr->inv, gr->xf, o, ro, rd, __uint_as_float((uint32_t)(key >> 32)), mk(ngv.x, ngv.y, ngv.z), p, nn);
+                    if (depth > -PT_EPSILON && (depth < best || (depth == best && j < hit))) { best = depth; hit = j; P = p; N = nn; face = -1; }
+                }
+                valid = fin;
+                lw = level;
+            }
+        } else {
+        const uint32_t have = isb ? nbox : nsph;
+        const uint32_t cnt = have < 64u ? have : 64u;
+        valid = lane < cnt;
+        const uint32_t pos = isb ? (have - cnt + lane) : (kPCap - 1u - (have - cnt + lane));
+        if (isb) nbox -= cnt; else nsph -= cnt;
+#ifdef PT_CULL_STATS
+        qstat(isb ? 10 : 12, 1ull); qstat(isb ? 11 : 13, (unsigned long long)cnt);
+#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (PT_P_SPLIT || NEE) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, PT_SELF_SCOPE);            // the parked words of earlier groups have landed (vmcnt 0) ...
@@ -320,25 +521,20 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : NEE ? 5 : 6) void k_path_q(SegAr
             j = (int)(jl & 0xFFu);
             level = jl >> 8;
         }
-        const uint32_t lw = level;                                            // NEE: the level word (level | shadow << 8 | count-emission << 9 | light << 10)
+        lw = level;
         if constexpr (NEE) level &= 0xFFu;
         __builtin_amdgcn_wave_barrier();
-        float best;
-        int hit, face = -1;
-        f3 P = mk(0, 0, 0), N = mk(0, 0, 0);
         {
             const GeomRec *gr = lg + j;
             float depth = -1.0f;
-            const bool jm = MESH && ((meshbits >> j) & 1u);
             if (isb) { if (valid) depth = box_test_face(gr->inv, gr->xf, gr->inside_hits, o, d, P, face); }
-            else {
-                if (!MESH || __any(valid && !jm)) { if (valid && !jm) depth = sphere_test(gr->inv, gr->xf, o, d, P, N); }
-                if (MESH) { if (__any(valid && jm)) { if (valid && jm) depth = mesh_test(gr, o, d, P, N); } }
-            }
+            else { if (valid) depth = sphere_test(gr->inv, gr->xf, o, d, P, N); }
             const bool wins = valid && depth > -PT_EPSILON && depth < kInf;
             best = wins ? depth : kInf;
             hit = wins ? j : -1;
         }
+        }
+        bool tomesh = false;                                                  // MESH: the next candidate is a mesh: the ray goes on the mesh stack
         if (__any(valid && mask != 0u)) {
             bool active = valid;
             for (;;) {
@@ -361,18 +557,24 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : NEE ? 5 : 6) void k_path_q(SegAr
                 active = next_j >= 0;
                 if (!__any(active)) break;
                 if (active) { j = next_j; mask &= ~(1u << next_j); }
+                if constexpr (MESH) {
+                    if (active && ((meshbits >> j) & 1u)) { tomesh = true; active = false; }
+                    if (!__any(active)) break;
+                }
                 const bool jb = (boxbits >> j) & 1u;
-                const bool jm = MESH && ((meshbits >> j) & 1u);
                 const GeomRec *gr = lg + j;
                 f3 p = mk(0, 0, 0), nn = mk(0, 0, 0);
                 int fc = -1;
                 float depth = -1.0f;
                 if (__any(active && jb)) { if (active && jb) depth = box_test_face(gr->inv, gr->xf, gr->inside_hits, o, d, p, fc); }
-                if (__any(active && !jb && !jm)) { if (active && !jb && !jm) depth = sphere_test(gr->inv, gr->xf, o, d, p, nn); }
-                if (MESH) { if (__any(active && jm)) { if (active && jm) depth = mesh_test(gr, o, d, p, nn); } }
+                if (__any(active && !jb)) { if (active && !jb) depth = sphere_test(gr->inv, gr->xf, o, d, p, nn); }
                 const bool wins = active && depth > -PT_EPSILON && (depth < best || (depth == best && j < hit));
                 if (wins) { best = depth; hit = j; P = p; N = nn; face = fc; }
             }
+        }
+        if constexpr (MESH) {
+            mesh_push(tomesh, o, d, thr, pv, mask, (uint32_t)j | (level << 8), best, hit, face, P, N, 0, kMeshNoHit, 0u);
+            if (tomesh) hit = -1;                                             // (not shaded in this turn)
         }
 #ifdef PT_CULL_STATS
         qstat(14, (unsigned long long)__popcll(__ballot(hit >= 0)));

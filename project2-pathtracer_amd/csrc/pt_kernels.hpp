@@ -797,6 +797,29 @@ __host__ __device__ inline uint32_t p_cursor_offset(int G, int M) { return q_lds
 __host__ __device__ inline uint32_t p_queue_offset(int G, int M) { return p_cursor_offset(G, M); }
 __host__ __device__ inline uint32_t p_lds_bytes(int G, int M) { return p_queue_offset(G, M) + (uint32_t)kWaves * kPCap * kPFields * 4u; }
 
+// k_path_q<MESH>: rays whose next candidate is a MESH primitive wait on a third typed stack, in the wave's arena behind the
+// parked words (field f of entry s at moff + f * kMStack + s): the ray's whole test state -- what a queue record holds, the
+// best hit so far (depth, primitive, face, P, N) and the traversal's own state (node cursor, best triangle as a 64-bit key
+// t-bits << 32 | index in the file, its position in the blob) -- so that a traversal can be interrupted and resumed.
+// A MESH turn pops 64 of them and works the threaded BVHs off in two dense stages: WALK (lane = ray, one node per trip; a
+// leaf becomes a (ray lane, first triangle, count) pair in LDS) and TRI (lane = one (ray, triangle) pair: the ray comes
+// over from its lane by bpermute, the result goes into the ray's key by an LDS atomic min).
+#ifndef PT_MESH_TURN
+#define PT_MESH_TURN 128                 // a MESH turn runs when this many rays wait (or nothing else can run): 64 are popped, the
+#endif                                   //   others are the reserve that lets a thinned-out WALK stop (kMeshMinWalk)
+#ifndef PT_MESH_MIN_WALK
+#define PT_MESH_MIN_WALK 24
+#endif
+constexpr uint32_t kMeshTurn = PT_MESH_TURN;
+constexpr uint32_t kMStack = kMeshTurn + 128;   // entries (bound: below kMeshTurn before a push of at most 64; a MESH turn pops 64 and pushes fewer than 64 + 64)
+constexpr uint32_t kMFields = 24;        // o d thr pixelword mask candidate|level<<8 | best hit|face P N | node keylo keyhi position
+constexpr uint32_t kMPairs = 128;        // (ray, triangle) pairs per wave in LDS
+constexpr uint32_t kMScratchBytes = 64u * 8u + 64u * 4u + kMPairs * 4u;     // keys, positions, pairs
+constexpr uint32_t kMeshMinWalk = PT_MESH_MIN_WALK;   // a WALK below this many lanes stops while other rays wait: its rays go back with their cursors
+constexpr int kMeshPairTris = 1 << 24;   // a pair entry holds lane (6 bits), triangles left in the leaf (2), triangle (24)
+__host__ __device__ inline uint32_t p_mesh_offset(int G, int M) { return (p_lds_bytes(G, M) + 15u) & ~15u; }
+__host__ __device__ inline uint32_t p_mesh_lds_bytes(int G, int M) { return p_mesh_offset(G, M) + (uint32_t)kWaves * kMScratchBytes; }
+
 
 struct FoldArgs {
     float *image;

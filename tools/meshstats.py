@@ -1,5 +1,5 @@
-"""Traversal statistics of the MESH primitives in the whole-path kernel (k_path_q<MESH>): how full the waves are while the per-lane
-threaded-BVH walk of mesh_test runs.  Needs a stats build:
+"""Traversal statistics of the MESH primitives in the whole-path kernel (k_path_q<MESH>): how full the waves are in the two stages
+of a MESH turn (WALK: lane = ray, one BVH node per trip; TRI: lane = one (ray, triangle) pair).  Needs a stats build:
   tools/build_variant.sh meshstats -DPT_CULL_STATS -DPT_MESH_STATS ;  PTMI355_LIB=.../build/variants/meshstats.so python3 tools/meshstats.py [scene]"""
 import ctypes as C, importlib, os, sys
 sys.path.insert(0, os.getcwd())
@@ -15,6 +15,7 @@ s = [int(v) for v in out]
 live = sum(int(st.live[k]) for k in range(8))
 d = lambda a, b: a / max(b, 1)
 print(scene, "live ray-bounces", live)
-print("mesh_test calls (wave level) per 64 live ray-bounces %.3f at %.1f lanes" % (s[0] / (live / 64.0), d(s[1], s[0])))
-print("BVH node visits: %.1f wave trips per call at %.1f lanes active (%.1f node visits per ray that enters a mesh test)" % (d(s[2], s[0]), d(s[3], s[2]), d(s[3], s[1])))
-print("triangle tests per ray that enters a mesh test %.2f" % d(s[4], s[1]))
+print("MESH turns per 64 live ray-bounces %.3f at %.1f lanes (rays that enter a mesh stage per live ray-bounce %.3f)" % (s[0] / (live / 64.0), d(s[1], s[0]), d(s[1], live)))
+print("WALK: %.1f trips per turn at %.1f lanes (%.1f node visits per ray of a turn)" % (d(s[2], s[0]), d(s[3], s[2]), d(s[3], s[1])))
+print("TRI: %.2f groups per turn at %.1f lanes (%.2f triangle tests per ray of a turn)" % (d(s[5], s[0]), d(s[4], s[5]), d(s[4], s[1])))
+print("interrupted traversals that went back on the mesh stack: %.3f per ray of a turn" % d(s[6], s[1]))
