@@ -1033,7 +1033,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         c->grid_path = c->n_cu * occ;
         c->path_waves = (uint32_t)kWaves;
         const size_t extra = c->pathq_nee ? kNeeExtraFields : 0;
-        c->arena_bytes = (size_t)c->grid_path * kWaves * (((size_t)kSFields + extra) * kStack + ((size_t)kPParked + extra) * kPCap +
+        c->arena_bytes = (size_t)c->grid_path * kWaves * (((size_t)kSFields + extra) * (kStack + (c->queue_mesh ? kMStack : 0u)) + ((size_t)kPParked + extra) * kPCap +
                                                            (c->queue_mesh ? (size_t)kMFields * kMStack : 0)) * sizeof(float);
         HIPCHK(hipMalloc(&c->d_arena, c->arena_bytes));
         HIPCHK(hipMalloc(&c->d_tickets, (size_t)kTicketCtrs * kTicketStride * sizeof(uint32_t)));

@@ -50,20 +50,22 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : NEE ? 5 : 6) void k_path_q(SegAr
     const uint32_t wslot = blockIdx.x * kWaves + wave;
     const uint32_t D = pa.depth;
     float *q = reinterpret_cast<float *>(smem + p_queue_offset(a.G, a.M)) + (size_t)wave * kPCap * kPFields;
-    // the wave's arena: its stack (field f of slot s at woff + f * kStack + s), then what the queue records park (field f of record r
+    // the wave's arena: its stack (field f of slot s at woff + f * KS + s), then what the queue records park (field f of record r
     // at poff + f * kPCap + r)
-    const uint32_t wave_floats = SF * kStack + PF * kPCap + (MESH ? kMFields * kMStack : 0u);
+    // (MESH: the rays on the mesh stack -- up to kMStack -- are part of the population that may end up on the stack of survivors)
+    constexpr uint32_t KS = MESH ? kStack + kMStack : kStack;
+    const uint32_t wave_floats = SF * KS + PF * kPCap + (MESH ? kMFields * kMStack : 0u);
     const bool ub = pa.arena_bytes != 0u;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pa.arena, 0, pa.arena_bytes, 0x00020000);
     const uint32_t woff = wslot * wave_floats;             // in floats (buffer path: arena below 4 GiB)
     auto ring_ld = [&](uint32_t off, uint32_t f) -> float {         // off = float index of field 0 of the slot
-        return ub ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off * 4u, f * kStack * 4u, 0)) : pa.arena[(size_t)off + f * kStack];
+        return ub ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off * 4u, f * KS * 4u, 0)) : pa.arena[(size_t)off + f * KS];
     };
     auto ring_st = [&](uint32_t off, uint32_t f, float v) {
-        if (ub) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, off * 4u, f * kStack * 4u, 0);
-        else pa.arena[(size_t)off + f * kStack] = v;
+        if (ub) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, off * 4u, f * KS * 4u, 0);
+        else pa.arena[(size_t)off + f * KS] = v;
     };
-    const uint32_t poff = woff + SF * kStack;
+    const uint32_t poff = woff + SF * KS;
     auto park_ld = [&](uint32_t pos, uint32_t f) -> float {
         return ub ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (poff + pos) * 4u, f * kPCap * 4u, 0)) : pa.arena[(size_t)poff + pos + f * kPCap];
     };
@@ -668,7 +670,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : NEE ? 5 : 6) void k_path_q(SegAr
             const u64 ballot = __ballot(to_stack);
             if (ballot) {
                 const uint32_t n = (uint32_t)__popcll(ballot);
-                if (sp + n > kStack) { if (lane == 0) *pa.error = 2u; }
+                if (sp + n > KS) { if (lane == 0) *pa.error = 2u; }
                 else {
                     if (to_stack) {
                         const uint32_t off = woff + sp + wave_rank(ballot);
@@ -743,7 +745,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : NEE ? 5 : 6) void k_path_q(SegAr
         const u64 ballot = __ballot(onward);
         if (ballot) {
             const uint32_t n = (uint32_t)__popcll(ballot);
-            if (sp + n > kStack) { if (lane == 0) *pa.error = 2u; }        // never: see the bound above
+            if (sp + n > KS) { if (lane == 0) *pa.error = 2u; }        // never: see the bound above
             else {
                 if (onward) {
                     const uint32_t off = woff + sp + wave_rank(ballot);

@@ -644,7 +644,9 @@ constexpr uint32_t kPParked = PT_P_SPLIT ? 4 : 0;    // tx ty tz pixelword per r
 #ifndef PT_STACK_SLOTS
 #define PT_STACK_SLOTS 256               // a smaller value is a test build: it provokes the overflow guard (tests/test_gpu_round3.py)
 #endif
-constexpr uint32_t kStack = PT_STACK_SLOTS;   // rays on a wave's stack (bound: 63 + two pops of 64)
+constexpr uint32_t kStack = PT_STACK_SLOTS;   // rays on a wave's stack.  Bound = the wave's whole population: camera rays only enter while the stack holds
+                                              //   fewer than 64 rays and the queues at most kPCap - 64 records: 63 + 74 + 64 = 201 rays in all, wherever they
+                                              //   sit later (k_path_q<MESH>: + the kMStack rays of the mesh stack, so its stack is that much deeper)
 constexpr uint32_t kSFields = 11;        // ox oy oz dx dy dz tx ty tz pixelword level
 constexpr uint32_t kTicketCtrs = 16, kTicketStride = 64;
 constexpr uint32_t kJobMax = 128;        // camera rays per job: about 1/48 of a wave's share of the launch, 64 .. kJobMax

@@ -112,3 +112,45 @@ def test_larger_mesh_and_odd_scales(pt):
         assert [st.live[k] for k in range(6)] == [int(x) for x in live], factor
         assert np.array_equal(tr.image(), want), factor
         tr.close()
+
+
+@pytest.mark.parametrize("workload", ["mesh", "mesh5k"])
+def test_mesh_stages_at_full_size_equal_the_per_bounce_kernels(pt, workload):
+    """k_path_q<MESH> at 1920x1080: every wave's mesh stack fills, so MESH turns run with a reserve of waiting rays and a WALK that
+    has thinned out is INTERRUPTED -- its rays go back on the stack with their node cursor and best triangle and are resumed in a
+    later turn (small frames never get there).  Image and live counts must equal those of the per-bounce kernels, whose per-lane
+    mesh_test is checked against the oracle above; twice, because a race would show as a difference between runs."""
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    sf = pt.SceneFile(os.path.join(root, bench.WORKLOADS[workload][0]))
+    geoms, mats, cam = sf.flatten(0)
+    cam.resolution[0], cam.resolution[1] = 1920.0, 1080.0
+    res = []
+    for ordering in (0, 2, 2):
+        tr = pt.PathTracer(pt.default_config(max_depth=8, ordering=ordering))
+        tr.set_meshes(sf.meshes())
+        tr.upload(geoms, mats, cam)
+        tr.set_image(None)
+        tr.render(1, 2)
+        st = tr.stats()
+        res.append(([int(st.live[k]) for k in range(9)], tr.image().copy()))
+        tr.close()
+    for live, img in res[1:]:
+        assert live == res[0][0]
+        assert np.array_equal(img, res[0][1])
+
+
+def test_interrupted_mesh_traversals_match_the_oracle(pt):
+    """The same mechanism against the oracle itself: one block per CU and a mid-sized frame give every wave a few hundred rays, enough
+    for its mesh stack to hold the reserve that lets WALKs be interrupted (tools/meshstats.py counts them on a stats build)."""
+    sc = orc.load_golden_scene("cornell_mesh").with_resolution(640, 360)
+    tr = make_tracer(sc, depth=5, ordering=2, blocks_per_cu=1)
+    tr.set_image(None)
+    tr.render(1, 1)
+    want, live = orc.render(sc, oracle_config(5), 1, 1)
+    st = tr.stats()
+    assert [st.live[k] for k in range(6)] == [int(v) for v in live]
+    assert np.array_equal(tr.image(), want)
+    tr.close()
