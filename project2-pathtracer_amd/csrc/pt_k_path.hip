@@ -382,30 +382,33 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : NEE ? 5 : 6) void k_path_q(SegAr
                     if (op == 0) {
                         // -------------------------------------------------------- WALK: lane = ray, one node of its mesh's threaded BVH
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                        for (uint32_t rep = 0; rep < kMeshWalkSteps; ++rep) {               // (several nodes per trip of the dispatcher)
 #ifdef PT_MESH_STATS
-                        if (lane == 0) { atomicAdd(&g_cull_stats[2], 1ull); atomicAdd(&g_cull_stats[3], (unsigned long long)nw); }
+                            { const u64 sb2 = __ballot(node >= 0); if (lane == 0) { atomicAdd(&g_cull_stats[2], 1ull); atomicAdd(&g_cull_stats[3], (unsigned long long)__popcll(sb2)); } }
 #endif
-                        bool leafhit = false;
-                        uint32_t e = 0u;
-                        if (node >= 0) {
-                            const float bt = __uint_as_float((uint32_t)(mkey[lane] >> 32));      // the ray's best triangle so far
-                            const float4 lo = *reinterpret_cast<const float4 *>(nodes[node].bmin);      // bmin.xyz, skip
-                            const float4 hi = *reinterpret_cast<const float4 *>(nodes[node].bmax);      // bmax.xyz, leaf
-                            const float bl[3] = {lo.x, lo.y, lo.z}, bh[3] = {hi.x, hi.y, hi.z};
-                            float tn;
-                            const bool in = cull_box(bl, bh, cr, tn) && !(tn > bt);
-                            const int skip = __float_as_int(lo.w), leaf = __float_as_int(hi.w);
-                            if (!in) node = skip;
-                            else if (leaf < 0) node = node + 1;
-                            else {
-                                leafhit = true;
-                                e = lane | ((((uint32_t)leaf >> 27) - 1u) << 6) | (((uint32_t)leaf & 0xFFFFFFu) << 8);
-                                node = skip;
+                            bool leafhit = false;
+                            uint32_t e = 0u;
+                            if (node >= 0) {
+                                const float bt = __uint_as_float((uint32_t)(mkey[lane] >> 32));      // the ray's best triangle so far
+                                const float4 lo = *reinterpret_cast<const float4 *>(nodes[node].bmin);      // bmin.xyz, skip
+                                const float4 hi = *reinterpret_cast<const float4 *>(nodes[node].bmax);      // bmax.xyz, leaf
+                                const float bl[3] = {lo.x, lo.y, lo.z}, bh[3] = {hi.x, hi.y, hi.z};
+                                float tn;
+                                const bool in = cull_box(bl, bh, cr, tn) && !(tn > bt);
+                                const int skip = __float_as_int(lo.w), leaf = __float_as_int(hi.w);
+                                if (!in) node = skip;
+                                else if (leaf < 0) node = node + 1;
+                                else {
+                                    leafhit = true;
+                                    e = lane | ((((uint32_t)leaf >> 27) - 1u) << 6) | (((uint32_t)leaf & 0xFFFFFFu) << 8);
+                                    node = skip;
+                                }
                             }
+                            const u64 lb = __ballot(leafhit);
+                            if (leafhit) mpair[npairs + wave_rank(lb)] = e;
+                            npairs += (uint32_t)__popcll(lb);
                         }
-                        const u64 lb = __ballot(leafhit);
-                        if (leafhit) mpair[npairs + wave_rank(lb)] = e;
-                        npairs += (uint32_t)__popcll(lb);
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                     } else {

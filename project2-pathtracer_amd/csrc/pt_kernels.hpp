@@ -815,7 +815,11 @@ __host__ __device__ inline uint32_t p_lds_bytes(int G, int M) { return p_queue_o
 constexpr uint32_t kMeshTurn = PT_MESH_TURN;
 constexpr uint32_t kMStack = kMeshTurn + 128;   // entries (bound: below kMeshTurn before a push of at most 64; a MESH turn pops 64 and pushes fewer than 64 + 64)
 constexpr uint32_t kMFields = 24;        // o d thr pixelword mask candidate|level<<8 | best hit|face P N | node keylo keyhi position
-constexpr uint32_t kMPairs = 128;        // (ray, triangle) pairs per wave in LDS
+#ifndef PT_MESH_WALK_STEPS
+#define PT_MESH_WALK_STEPS 3
+#endif
+constexpr uint32_t kMeshWalkSteps = PT_MESH_WALK_STEPS;      // BVH nodes a WALK lane visits per trip of the stage dispatcher
+constexpr uint32_t kMPairs = 64u + 64u * kMeshWalkSteps;     // (ray, triangle) pairs per wave in LDS: fewer than 64 before a trip adds up to 64 per step
 constexpr uint32_t kMScratchBytes = 64u * 8u + 64u * 4u + kMPairs * 4u;     // keys, positions, pairs
 constexpr uint32_t kMeshMinWalk = PT_MESH_MIN_WALK;   // a WALK below this many lanes stops while other rays wait: its rays go back with their cursors
 constexpr int kMeshPairTris = 1 << 24;   // a pair entry holds lane (6 bits), triangles left in the leaf (2), triangle (24)
