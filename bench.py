@@ -255,6 +255,7 @@ def main():
         child = subprocess.run(cmd, env=env)
         raise SystemExit(child.returncode)
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # (the host driver only supports dmabuf IPC: RCCL needs it under any launcher)
     import torch
     import torch.distributed as dist
 

@@ -368,10 +368,12 @@ void build_grid(const std::vector<GeomRec> &g, int G, int density, size_t max_by
 }
 
 // ---- MESH: threaded BVH over the triangles of one mesh (object space), built at upload ----------------------
-// Median split of the triangle centroids along the widest axis, <= 4 triangles per leaf, nodes in depth-first
+// Cuts chosen by the surface-area heuristic over the centroid order of each axis, <= 4 triangles per leaf, nodes in depth-first
 // order with skip links (traversal needs no stack).  Boxes are the exact float min/max of the member vertices,
 // inflated by 1e-5 * (1 + largest |coordinate|): the slab test adds its own relative margins (cull_box).
 struct MeshBuild {
+    static constexpr int kSweepDepth = 48;      // lopsided cuts (degenerate meshes) end here: below, medians keep the recursion at log n
+    static constexpr int kSweepMax = 1 << 16;   // nodes above this many triangles are cut at the median (a sweep of every split costs n log n per node)
     const float *v;
     const int *idx;
     std::vector<int> order;                  // triangle permutation (leaf ranges index into it)
@@ -385,7 +387,7 @@ struct MeshBuild {
                 for (int k = 0; k < 3; ++k) { lo[k] = std::fmin(lo[k], p[k]); hi[k] = std::fmax(hi[k], p[k]); }
             }
     }
-    int emit(int first, int count, int parent_skip) {
+    int emit(int first, int count, int parent_skip, int depth = 0) {
         const int id = (int)nodes.size();
         nodes.emplace_back();
         float lo[3], hi[3];
@@ -397,18 +399,50 @@ struct MeshBuild {
         nodes[id].skip = parent_skip;
         if (count <= 4) { nodes[id].leaf = first | (count << 27); return id; }
         nodes[id].leaf = -1;
-        int axis = 0;
-        float ext = -1.0f;
-        for (int k = 0; k < 3; ++k) {
-            float cmin = 3e38f, cmax = -3e38f;
-            for (int i = first; i < first + count; ++i) { cmin = std::fmin(cmin, cen[3 * order[i] + k]); cmax = std::fmax(cmax, cen[3 * order[i] + k]); }
-            if (cmax - cmin > ext) { ext = cmax - cmin; axis = k; }
+        // where to cut: the surface-area heuristic over every split of the centroid order of each axis (cost = area x count of the
+        // two sides), ties to the lower axis and the earlier split; above kSweepMax triangles the median along the widest axis
+        int half = count / 2;
+        auto by_axis = [&](int axis) {
+            return [this, axis](int x, int y) { return cen[3 * x + axis] < cen[3 * y + axis] || (cen[3 * x + axis] == cen[3 * y + axis] && x < y); };
+        };
+        if (count <= kSweepMax && depth < kSweepDepth) {
+            int best_axis = 0;
+            double best_cost = 1e300;
+            std::vector<double> right(count);
+            for (int k = 0; k < 3; ++k) {
+                std::sort(order.begin() + first, order.begin() + first + count, by_axis(k));
+                float lo2[3] = {3e38f, 3e38f, 3e38f}, hi2[3] = {-3e38f, -3e38f, -3e38f};
+                auto grow = [&](int i) {
+                    for (int c = 0; c < 3; ++c) {
+                        const float *p = v + 3 * idx[3 * order[first + i] + c];
+                        for (int q = 0; q < 3; ++q) { lo2[q] = std::fmin(lo2[q], p[q]); hi2[q] = std::fmax(hi2[q], p[q]); }
+                    }
+                };
+                auto area = [&]() {
+                    const double dx = (double)hi2[0] - lo2[0], dy = (double)hi2[1] - lo2[1], dz = (double)hi2[2] - lo2[2];
+                    return dx * dy + dy * dz + dz * dx;
+                };
+                for (int i = count - 1; i >= 1; --i) { grow(i); right[i] = area(); }
+                for (int q = 0; q < 3; ++q) { lo2[q] = 3e38f; hi2[q] = -3e38f; }
+                for (int i = 1; i < count; ++i) {
+                    grow(i - 1);
+                    const double cost = area() * i + right[i] * (count - i);
+                    if (cost < best_cost) { best_cost = cost; best_axis = k; half = i; }
+                }
+            }
+            std::sort(order.begin() + first, order.begin() + first + count, by_axis(best_axis));
+        } else {
+            int axis = 0;
+            float ext = -1.0f;
+            for (int k = 0; k < 3; ++k) {
+                float cmin = 3e38f, cmax = -3e38f;
+                for (int i = first; i < first + count; ++i) { cmin = std::fmin(cmin, cen[3 * order[i] + k]); cmax = std::fmax(cmax, cen[3 * order[i] + k]); }
+                if (cmax - cmin > ext) { ext = cmax - cmin; axis = k; }
+            }
+            std::nth_element(order.begin() + first, order.begin() + first + half, order.begin() + first + count, by_axis(axis));
         }
-        const int half = count / 2;
-        std::nth_element(order.begin() + first, order.begin() + first + half, order.begin() + first + count,
-                         [&](int x, int y) { return cen[3 * x + axis] < cen[3 * y + axis] || (cen[3 * x + axis] == cen[3 * y + axis] && x < y); });
-        const int left = emit(first, half, -2);                      // -2: "the right sibling", known once the left subtree is out
-        const int right = emit(first + half, count - half, parent_skip);
+        const int left = emit(first, half, -2, depth + 1);                      // -2: "the right sibling", known once the left subtree is out
+        const int right = emit(first + half, count - half, parent_skip, depth + 1);
         for (int k = left; k < right; ++k)
             if (nodes[k].skip == -2) nodes[k].skip = right;
         return id;

@@ -33,3 +33,5 @@ for f in sorted(glob.glob("gpurun_out/r03z_bench_*.log")):
             print(f.split("/")[-1], "ms/step", d["ms_per_step"], "Mray/s", d["value"], "frac", r["frac"], "spread", d["spread"], "hbm", (r.get("hbm_measured") or {}).get("frac_of_peak"), "valu", (r.get("valu_issue") or {}).get("frac"))
 PY
 timeout -k 10 300 python3 tools/shard_sim.py 1 ordering=2 > $OUT/r03z_shard_sim_c3.log 2>&1; tail -4 $OUT/r03z_shard_sim_c3.log
+timeout -k 10 200 python3 tools/launch_curve.py 8 > $OUT/r03z_launch_curve_8way.log 2>&1; tail -3 $OUT/r03z_launch_curve_8way.log
+timeout -k 10 200 python3 tools/launch_curve.py 1 > $OUT/r03z_launch_curve_1way.log 2>&1; tail -3 $OUT/r03z_launch_curve_1way.log
