@@ -391,8 +391,12 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : NEE ? 5 : 6) void k_path_q(SegAr
                             uint32_t e = 0u;
                             if (node >= 0) {
                                 const float bt = __uint_as_float((uint32_t)(mkey[lane] >> 32));      // the ray's best triangle so far
-                                const float4 lo = *reinterpret_cast<const float4 *>(nodes[node].bmin);      // bmin.xyz, skip
-                                const float4 hi = *reinterpret_cast<const float4 *>(nodes[node].bmax);      // bmax.xyz, leaf
+                                // (the blob is global memory: saying so gives global_load instead of flat_load, which also counts as an LDS access)
+                                typedef float nf4 __attribute__((ext_vector_type(4)));
+                                typedef const __attribute__((address_space(1))) nf4 *gf4;
+                                const gf4 np = (gf4)(uintptr_t)(nodes + node);
+                                const nf4 lo = np[0];                         // bmin.xyz, skip
+                                const nf4 hi = np[1];                         // bmax.xyz, leaf
                                 const float bl[3] = {lo.x, lo.y, lo.z}, bh[3] = {hi.x, hi.y, hi.z};
                                 float tn;
                                 const bool in = cull_box(bl, bh, cr, tn) && !(tn > bt);
@@ -436,8 +440,10 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : NEE ? 5 : 6) void k_path_q(SegAr
                         unsigned long long mykey = kMeshNoHit;
                         bool ok = false;
                         if (tv) {
-                            const float4 *tp = reinterpret_cast<const float4 *>(ptb + (unsigned long long)tri * sizeof(MeshTri));
-                            const float4 va = tp[0], vb = tp[1], vc = tp[2];
+                            typedef float nf4 __attribute__((ext_vector_type(4)));
+                            typedef const __attribute__((address_space(1))) nf4 *gf4;
+                            const gf4 tp = (gf4)(uintptr_t)(ptb + (unsigned long long)tri * sizeof(MeshTri));
+                            const nf4 va = tp[0], vb = tp[1], vc = tp[2];
                             const float t = triangle_test(mk(va.x, va.y, va.z), mk(vb.x, vb.y, vb.z), mk(vc.x, vc.y, vc.z), pro, prd);
                             ok = t > 0.0f;
                             mykey = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(uint32_t)__float_as_int(va.w);

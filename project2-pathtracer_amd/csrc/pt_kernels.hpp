@@ -171,8 +171,12 @@ __device__ __forceinline__ float mesh_test(const GeomRec *g, f3 o, f3 d, f3 &P, 
 #ifdef PT_MESH_STATS
         { const unsigned long long act = __ballot(1); if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(act)) { atomicAdd(&g_cull_stats[2], 1ull); atomicAdd(&g_cull_stats[3], (unsigned long long)__popcll(act)); } }
 #endif
-        const float4 lo = *reinterpret_cast<const float4 *>(nodes[node].bmin);      // bmin.xyz, skip
-        const float4 hi = *reinterpret_cast<const float4 *>(nodes[node].bmax);      // bmax.xyz, leaf
+        // (the blob is global memory: saying so gives global_load instead of flat_load, which also counts as an LDS access)
+        typedef float nf4 __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(1))) nf4 *gf4;
+        const gf4 np = (gf4)(uintptr_t)(nodes + node);
+        const nf4 lo = np[0];                                                        // bmin.xyz, skip
+        const nf4 hi = np[1];                                                        // bmax.xyz, leaf
         const float bl[3] = {lo.x, lo.y, lo.z}, bh[3] = {hi.x, hi.y, hi.z};
         float tn;
         const bool in = cull_box(bl, bh, cr, tn) && !(tn > best);
@@ -184,8 +188,8 @@ __device__ __forceinline__ float mesh_test(const GeomRec *g, f3 o, f3 d, f3 &P, 
 #ifdef PT_MESH_STATS
             atomicAdd(&g_cull_stats[4], 1ull);
 #endif
-            const float4 *tp = reinterpret_cast<const float4 *>(tris + first + k);
-            const float4 a = tp[0], b = tp[1], c = tp[2];
+            const gf4 tp = (gf4)(uintptr_t)(tris + first + k);
+            const nf4 a = tp[0], b = tp[1], c = tp[2];
             const float t = triangle_test(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), ro, rd);
             const int idx = __float_as_int(a.w);
             if (t > 0.0f && (t < best || (t == best && idx < widx))) { best = t; win = first + k; widx = idx; }
