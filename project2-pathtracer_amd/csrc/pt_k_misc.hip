@@ -19,8 +19,10 @@ __global__ __launch_bounds__(kBlock) void k_fold(FoldArgs a) {
     float r = a.image[p], g = a.image[p + 1], b = a.image[p + 2];
     for (uint32_t s = 0; s < a.batch; ++s) {
         float *q = a.planes + (size_t)s * a.plane_stride + (size_t)gid * 3;       // planes hold the owned pixels only
-        r = r + q[0]; g = g + q[1]; b = b + q[2];
-        q[0] = 0.0f; q[1] = 0.0f; q[2] = 0.0f;
+        const float qr = q[0], qg = q[1], qb = q[2];
+        r = r + qr; g = g + qg; b = b + qb;
+        // most entries are still zero (only paths that met an emitter wrote): clearing only the others saves most of the fold's writes
+        if (qr != 0.0f || qg != 0.0f || qb != 0.0f) { q[0] = 0.0f; q[1] = 0.0f; q[2] = 0.0f; }
     }
     a.image[p] = r; a.image[p + 1] = g; a.image[p + 2] = b;
 }
