@@ -154,3 +154,50 @@ def test_interrupted_mesh_traversals_match_the_oracle(pt):
     assert [st.live[k] for k in range(6)] == [int(v) for v in live]
     assert np.array_equal(tr.image(), want)
     tr.close()
+
+
+def _degenerate_meshes():
+    """meshes that stress the BVH builder's cuts and the tie rule, in the unit cube around the origin (object space)"""
+    rng = np.random.default_rng(12)
+    out = {}
+    # 200 copies of ONE triangle (all centroids equal: every cut is a tie) in front of 50 copies of a second one: the earliest
+    # triangle of the file must win every tie on t
+    a = np.array([[-0.4, -0.4, 0.1], [0.4, -0.4, 0.1], [0.0, 0.45, 0.1]], np.float32)
+    b = a + np.float32([0.0, 0.0, -0.3])
+    out["copies"] = (np.concatenate([a, b]), np.array([[0, 1, 2]] * 200 + [[3, 4, 5]] * 50, np.int32))
+    # a strip of thin slivers along x: lopsided surface-area cuts, deep tree
+    n = 300
+    xs = np.linspace(-0.5, 0.5, n + 1, dtype=np.float32) ** 3 * 4.0
+    v = np.stack([np.stack([xs, np.full(n + 1, -0.3, np.float32), np.zeros(n + 1, np.float32)], 1),
+                  np.stack([xs, np.full(n + 1, 0.3, np.float32), 0.2 * np.sin(np.arange(n + 1, dtype=np.float32))], 1)], 1).reshape(-1, 3)
+    f = np.array([[2 * i, 2 * i + 2, 2 * i + 1] for i in range(n)] + [[2 * i + 1, 2 * i + 2, 2 * i + 3] for i in range(n)], np.int32)
+    out["strip"] = (v.astype(np.float32), f)
+    # one triangle; five triangles (one cut above the leaf size); a cloud of random small triangles, some of zero area
+    out["single"] = (a.copy(), np.array([[0, 1, 2]], np.int32))
+    v5 = rng.uniform(-0.5, 0.5, (15, 3)).astype(np.float32)
+    out["five"] = (v5, np.arange(15, dtype=np.int32).reshape(5, 3))
+    c = rng.uniform(-0.45, 0.45, (120, 1, 3)).astype(np.float32)
+    vc = (c + rng.uniform(-0.08, 0.08, (120, 3, 3)).astype(np.float32)).reshape(-1, 3)
+    fc = np.arange(360, dtype=np.int32).reshape(120, 3)
+    fc[::17, 2] = fc[::17, 1]                                # zero-area triangles
+    out["cloud"] = (vc, fc)
+    return out
+
+
+@pytest.mark.parametrize("ordering", [0, 2])
+def test_degenerate_meshes_match_the_oracle(pt, ordering):
+    """BVH cuts by the surface-area heuristic on meshes that give it nothing to choose (identical centroids), lopsided cuts
+    (slivers), trees of one node, zero-area triangles -- and the tie rule of the (t, index) keys: of coincident triangles
+    the earliest in the file wins.  Each mesh takes the place of the icosphere of the mesh scene, one at a time."""
+    base = orc.load_golden_scene("cornell_mesh").with_resolution(160, 120)
+    gi = base.meshes[0][0]
+    for name, (v, f) in _degenerate_meshes().items():
+        sc = orc.Scene(base.geoms, base.materials, base.camera, meshes=[(gi, v, f)] + base.meshes[1:])
+        tr = make_tracer(sc, depth=5, ordering=ordering)
+        tr.set_image(None)
+        tr.render(1, 2)
+        want, live = orc.render(sc, oracle_config(5), 1, 2)
+        st = tr.stats()
+        assert [st.live[k] for k in range(6)] == [int(x) for x in live], (name, ordering)
+        assert np.array_equal(tr.image(), want), (name, ordering)
+        tr.close()
