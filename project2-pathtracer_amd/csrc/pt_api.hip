@@ -369,7 +369,7 @@ void build_grid(const std::vector<GeomRec> &g, int G, int density, size_t max_by
 
 // ---- MESH: threaded BVH over the triangles of one mesh (object space), built at upload ----------------------
 // Cuts chosen by the surface-area heuristic over the centroid order of each axis, <= 4 triangles per leaf, nodes in depth-first
-// order with skip links (traversal needs no stack).  Boxes are the exact float min/max of the member vertices,
+// order with skip links per direction octant (traversal needs no stack and visits the near child first).  Boxes are the exact float min/max of the member vertices,
 // inflated by 1e-5 * (1 + largest |coordinate|): the slab test adds its own relative margins (cull_box).
 struct MeshBuild {
     static constexpr int kSweepDepth = 48;      // lopsided cuts (degenerate meshes) end here: below, medians keep the recursion at log n
@@ -387,7 +387,7 @@ struct MeshBuild {
                 for (int k = 0; k < 3; ++k) { lo[k] = std::fmin(lo[k], p[k]); hi[k] = std::fmax(hi[k], p[k]); }
             }
     }
-    int emit(int first, int count, int parent_skip, int depth = 0) {
+    int emit(int first, int count, int depth = 0) {
         const int id = (int)nodes.size();
         nodes.emplace_back();
         float lo[3], hi[3];
@@ -396,9 +396,11 @@ struct MeshBuild {
         for (int k = 0; k < 3; ++k) maxabs = std::fmax(maxabs, std::fmax(std::fabs(lo[k]), std::fabs(hi[k])));
         const float infl = 1e-5f * (1.0f + maxabs);
         for (int k = 0; k < 3; ++k) { nodes[id].bmin[k] = lo[k] - infl; nodes[id].bmax[k] = hi[k] + infl; }
-        nodes[id].skip = parent_skip;
+        nodes[id].far = 0;
+        for (int o = 0; o < 8; ++o) nodes[id].skip[o] = -1;
         if (count <= 4) { nodes[id].leaf = first | (count << 27); return id; }
         nodes[id].leaf = -1;
+        int cut_axis = 0;
         // where to cut: the surface-area heuristic over every split of the centroid order of each axis (cost = area x count of the
         // two sides), ties to the lower axis and the earlier split; above kSweepMax triangles the median along the widest axis
         int half = count / 2;
@@ -431,6 +433,7 @@ struct MeshBuild {
                 }
             }
             std::sort(order.begin() + first, order.begin() + first + count, by_axis(best_axis));
+            cut_axis = best_axis;
         } else {
             int axis = 0;
             float ext = -1.0f;
@@ -440,16 +443,16 @@ struct MeshBuild {
                 if (cmax - cmin > ext) { ext = cmax - cmin; axis = k; }
             }
             std::nth_element(order.begin() + first, order.begin() + first + half, order.begin() + first + count, by_axis(axis));
+            cut_axis = axis;
         }
-        const int left = emit(first, half, -2, depth + 1);                      // -2: "the right sibling", known once the left subtree is out
-        const int right = emit(first + half, count - half, parent_skip, depth + 1);
-        for (int k = left; k < right; ++k)
-            if (nodes[k].skip == -2) nodes[k].skip = right;
+        emit(first, half, depth + 1);                                   // the lower child: the next node
+        const int right = emit(first + half, count - half, depth + 1);
+        nodes[id].far = cut_axis | (right << 2);
         return id;
     }
 };
 
-// [MeshNode x nnodes (padded to a multiple of 2) | MeshTri x ntris] for one mesh; *tri_offset = byte offset of the triangles
+// [MeshNode x nnodes | MeshTri x ntris] for one mesh; *tri_offset = byte offset of the triangles
 std::vector<unsigned char> build_mesh_blob(const pt_context::HostMesh &hm, uint32_t *tri_offset) {
     MeshBuild mb;
     mb.v = hm.v.data(); mb.idx = hm.idx.data();
@@ -460,8 +463,20 @@ std::vector<unsigned char> build_mesh_blob(const pt_context::HostMesh &hm, uint3
         for (int k = 0; k < 3; ++k)
             mb.cen[3 * t + k] = (hm.v[3 * hm.idx[3 * t] + k] + hm.v[3 * hm.idx[3 * t + 1] + k] + hm.v[3 * hm.idx[3 * t + 2] + k]) * (1.0f / 3.0f);
     }
-    mb.emit(0, nt, -1);
-    const size_t nn = (mb.nodes.size() + 1) & ~(size_t)1;
+    mb.emit(0, nt);
+    // where a ray of direction octant o goes on after a node: the near child's successor is the far child, the far child's is
+    // its parent's (parents precede their children in the node order)
+    for (size_t n = 0; n < mb.nodes.size(); ++n) {
+        if (mb.nodes[n].leaf >= 0) continue;
+        const int axis = mb.nodes[n].far & 3, lo_child = (int)n + 1, hi_child = mb.nodes[n].far >> 2;
+        for (int o = 0; o < 8; ++o) {
+            const bool neg = (o >> axis) & 1;
+            const int near_c = neg ? hi_child : lo_child, far_c = neg ? lo_child : hi_child;
+            mb.nodes[near_c].skip[o] = far_c;
+            mb.nodes[far_c].skip[o] = mb.nodes[n].skip[o];
+        }
+    }
+    const size_t nn = mb.nodes.size();
     *tri_offset = (uint32_t)(nn * sizeof(MeshNode));
     std::vector<unsigned char> blob(nn * sizeof(MeshNode) + (size_t)nt * sizeof(MeshTri), 0);
     memcpy(blob.data(), mb.nodes.data(), mb.nodes.size() * sizeof(MeshNode));

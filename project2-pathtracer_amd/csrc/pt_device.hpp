@@ -227,11 +227,16 @@ struct __attribute__((aligned(16))) MeshTri {
     float e2[3]; float pad2;
     float ng[3]; float pad3;
 };
-// threaded BVH node (depth-first order): on a miss, or after a leaf, traversal continues at `skip` (-1 = done); an
-// inner node's first child is the next node.  leaf < 0: inner; else first triangle | count << 27.  32 bytes.
+// threaded BVH node (depth-first order, the child on the lower side of the cut first).  A ray visits the children of an inner
+// node NEAR SIDE FIRST -- the lower one first if it travels up the cut's axis, else the higher one -- so that a hit found early
+// prunes the far side; the order therefore depends on the octant of the ray's direction (bit k: d[k] < 0), and so does the node
+// at which traversal continues once a node's subtree is finished or the node is missed: skip[octant] (-1 = done).
+// leaf >= 0: first triangle | count << 27; leaf < 0: inner, far = axis of the cut | index of the higher child << 2 (the lower
+// child is the next node).  64 bytes.
 struct __attribute__((aligned(16))) MeshNode {
-    float bmin[3]; int skip;
-    float bmax[3]; int leaf;
+    float bmin[3]; int leaf;
+    float bmax[3]; int far;
+    int skip[8];
 };
 
 // two-sided Moeller-Trumbore in this exact expression order; returns t > 0 or -1

@@ -363,6 +363,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : NEE ? 5 : 6) void k_path_q(SegAr
                 const f3 ro = mul_point(gr->inv, o);                          // (mesh_test's own first lines)
                 const f3 rd = normalize(mul_vector(gr->inv, d));
                 const CullRay cr = make_cull_ray(ro, rd);
+                const int oct = (rd.x < 0.0f ? 1 : 0) | (rd.y < 0.0f ? 2 : 0) | (rd.z < 0.0f ? 4 : 0);      // near children first (MeshNode)
                 mkey[lane] = key;
                 mposn[lane] = mpos;
                 uint32_t npairs = 0u;
@@ -394,15 +395,17 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : NEE ? 5 : 6) void k_path_q(SegAr
                                 // (the blob is global memory: saying so gives global_load instead of flat_load, which also counts as an LDS access)
                                 typedef float nf4 __attribute__((ext_vector_type(4)));
                                 typedef const __attribute__((address_space(1))) nf4 *gf4;
+                                typedef const __attribute__((address_space(1))) int *gi1;
                                 const gf4 np = (gf4)(uintptr_t)(nodes + node);
-                                const nf4 lo = np[0];                         // bmin.xyz, skip
-                                const nf4 hi = np[1];                         // bmax.xyz, leaf
+                                const nf4 lo = np[0];                         // bmin.xyz, leaf
+                                const nf4 hi = np[1];                         // bmax.xyz, far
+                                const int skip = ((gi1)(uintptr_t)(nodes + node))[8 + oct];      // where this ray's octant goes on after the node
                                 const float bl[3] = {lo.x, lo.y, lo.z}, bh[3] = {hi.x, hi.y, hi.z};
                                 float tn;
                                 const bool in = cull_box(bl, bh, cr, tn) && !(tn > bt);
-                                const int skip = __float_as_int(lo.w), leaf = __float_as_int(hi.w);
+                                const int leaf = __float_as_int(lo.w), far = __float_as_int(hi.w);
                                 if (!in) node = skip;
-                                else if (leaf < 0) node = node + 1;
+                                else if (leaf < 0) node = ((oct >> (far & 3)) & 1) ? (far >> 2) : node + 1;      // the near child first
                                 else {
                                     leafhit = true;
                                     e = lane | ((((uint32_t)leaf >> 27) - 1u) << 6) | (((uint32_t)leaf & 0xFFFFFFu) << 8);

@@ -164,6 +164,7 @@ __device__ __forceinline__ float mesh_test(const GeomRec *g, f3 o, f3 d, f3 &P, 
     float best = 3.0e38f;
     int win = -1, widx = 0x7FFFFFFF;
     int node = 0;
+    const int oct = (rd.x < 0.0f ? 1 : 0) | (rd.y < 0.0f ? 2 : 0) | (rd.z < 0.0f ? 4 : 0);      // near children first (MeshNode)
 #ifdef PT_MESH_STATS
     { const unsigned long long act = __ballot(1); if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(act)) { atomicAdd(&g_cull_stats[0], 1ull); atomicAdd(&g_cull_stats[1], (unsigned long long)__popcll(act)); } }
 #endif
@@ -174,15 +175,17 @@ __device__ __forceinline__ float mesh_test(const GeomRec *g, f3 o, f3 d, f3 &P, 
         // (the blob is global memory: saying so gives global_load instead of flat_load, which also counts as an LDS access)
         typedef float nf4 __attribute__((ext_vector_type(4)));
         typedef const __attribute__((address_space(1))) nf4 *gf4;
+        typedef const __attribute__((address_space(1))) int *gi1;
         const gf4 np = (gf4)(uintptr_t)(nodes + node);
-        const nf4 lo = np[0];                                                        // bmin.xyz, skip
-        const nf4 hi = np[1];                                                        // bmax.xyz, leaf
+        const nf4 lo = np[0];                                                        // bmin.xyz, leaf
+        const nf4 hi = np[1];                                                        // bmax.xyz, far
+        const int skip = ((gi1)(uintptr_t)(nodes + node))[8 + oct];
         const float bl[3] = {lo.x, lo.y, lo.z}, bh[3] = {hi.x, hi.y, hi.z};
         float tn;
         const bool in = cull_box(bl, bh, cr, tn) && !(tn > best);
-        const int skip = __float_as_int(lo.w), leaf = __float_as_int(hi.w);
+        const int leaf = __float_as_int(lo.w), far = __float_as_int(hi.w);
         if (!in) { node = skip; continue; }
-        if (leaf < 0) { node = node + 1; continue; }
+        if (leaf < 0) { node = ((oct >> (far & 3)) & 1) ? (far >> 2) : node + 1; continue; }
         const int first = leaf & 0x7FFFFFF, cnt = (int)((uint32_t)leaf >> 27);
         for (int k = 0; k < cnt; ++k) {
 #ifdef PT_MESH_STATS
