@@ -201,3 +201,50 @@ def test_degenerate_meshes_match_the_oracle(pt, ordering):
         assert [st.live[k] for k in range(6)] == [int(x) for x in live], (name, ordering)
         assert np.array_equal(tr.image(), want), (name, ordering)
         tr.close()
+
+
+def test_many_overlapping_meshes_match_the_oracle(pt):
+    """Ten meshes (icospheres of 20..320 triangles and tori, glass / mirror / diffuse) that overlap and sit inside one another in the
+    Cornell room: rays leave one mesh for the next inside the same turn (a finished traversal whose next candidate is another
+    mesh goes straight back on the mesh stack), carry a best hit from a cube into a mesh test and out again.  Whole paths against
+    the oracle, and the pool of ray records at two bounces."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from make_scenes import icosphere, torus
+    base = orc.load_golden_scene("cornell_mesh").with_resolution(200, 150)
+    rng = np.random.default_rng(77)
+    xf, inv = np.zeros(16, np.float32), np.zeros(16, np.float32)
+    geoms = [g for g in base.geoms[:6]] + [base.geoms[9], base.geoms[10]]          # the room, the light, a sphere and a cube
+    meshes = []
+    shapes = [icosphere(0), icosphere(1), icosphere(2), icosphere(1), icosphere(2)]
+    tv, tf = torus(12, 8)
+    tri = []
+    for q in tf:                                             # the generator's quads, fanned like the loader does
+        tri += [(q[0], q[k], q[k + 1]) for k in range(1, len(q) - 1)]
+    shapes += [(tv, tri)] * 2 + [icosphere(0), icosphere(1), icosphere(2)]
+    for k, (v, f) in enumerate(shapes):
+        centre = (rng.uniform(-2.5, 2.5), rng.uniform(1.0, 6.0), rng.uniform(-2.0, 3.0)) if k % 3 else (0.3 * k - 1.0, 3.0 + 0.1 * k, 0.5)    # every third one nested around one spot
+        scale = [float(s) for s in rng.uniform(1.2, 3.5, 3)]
+        orc.lib().orc_build_transform(orc.vec3(*centre), orc.vec3(*[float(a) for a in rng.uniform(0, 180, 3)]), orc.vec3(*scale), orc.fptr(xf), orc.fptr(inv))
+        g = orc.Geom()
+        g.type, g.materialid = 2, [2, 4, 5, 1, 3][k % 5]
+        for i in range(16):
+            g.transform[i] = float(xf[i]); g.inverseTransform[i] = float(inv[i])
+        meshes.append((len(geoms), np.array(v, np.float32), np.array(f, np.int32)))
+        geoms.append(g)
+    sc = orc.Scene(geoms, base.materials, base.camera, meshes=meshes)
+    for ordering in (2, 0):
+        tr = make_tracer(sc, depth=7, ordering=ordering)
+        tr.set_image(None)
+        tr.render(1, 2)
+        want, live = orc.render(sc, oracle_config(7), 1, 2)
+        st = tr.stats()
+        assert [st.live[k] for k in range(8)] == [int(x) for x in live], ordering
+        assert np.array_equal(tr.image(), want), ordering
+        n, arrs, pix = tr.trace_pool(2, 2)
+        on, oarrs, opix = orc.trace_pool(sc, oracle_config(7), 2, 2)
+        if ordering:
+            order = np.argsort(pix, kind="stable")
+            pix, arrs = pix[order], [a[order] for a in arrs]
+        assert n == on and np.array_equal(pix, opix) and all(np.array_equal(a, b) for a, b in zip(arrs, oarrs)), ordering
+        tr.close()
