@@ -178,3 +178,30 @@ def test_whole_path_kernels_ray_records_match_the_oracle_pool(pt, name, w, h, bo
     assert np.array_equal(tr.image(), want)
     assert [int(tr.stats().live[k]) for k in range(9)] == [int(v) for v in live]
     tr.close()
+
+
+@pytest.mark.parametrize("ranks,workload,res,scene", [(4, "c3", "640x360", "cornell_mirror"), (3, "c4", "320x182", "random256")])
+def test_bench_more_ranks_gloo_rehearsal_frames_match_the_oracle(pt, ranks, workload, res, scene):
+    """The N > 1 path of bench.py with more ranks than the two of tests/test_gpu_round2.py, all on this box's one GPU over gloo
+    (at most five processes on the card at once): rows interleaved over 4 ranks on k_path_q, and over 3 ranks with an uneven
+    row count on k_path_w -- the frame rank 0 gathers is bit-identical to the oracle's."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["PT_BENCH_BACKEND"] = "gloo"
+    dump = os.path.join(root, "gpurun_out", "rehearsal_frame_%d.npy" % ranks)
+    os.makedirs(os.path.dirname(dump), exist_ok=True)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--steps", "4", "--warmup", "2", "--repeats", "2",
+                        "--workload", workload, "--no-cpu-baseline", "--resolution", res, "--dump-image", dump],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == ranks and out["scaling"] == "strong" and out["value"] > 0
+    w, h = [int(x) for x in res.split("x")]
+    got = np.load(dump)
+    want, _ = orc.render(orc.load_golden_scene(scene).with_resolution(w, h), oracle_config(8), 3, 4)
+    assert got.shape == want.shape and np.array_equal(got, want)
+
