@@ -356,10 +356,16 @@ void build_grid(const std::vector<GeomRec> &g, int G, int density, size_t max_by
         diag2 += (h[k] * n[k]) * (h[k] * n[k]);
     }
     ga.reach = (float)(8.0 * std::sqrt(diag2));
-    {   // the survivors' bins by walk length: short <= ~0.45 x the mean cell count per axis, middle <= twice that
+    {   // the survivors' bins by walk length: short <= 0.75 x the mean cell count per axis, middle <= 1.4 x (swept on configs[3]: DESIGN.md appendix B)
         const double navg = (n[0] + n[1] + n[2]) / 3.0;
-        const uint32_t b1 = (uint32_t)std::max(2.0, std::floor(0.45 * navg + 0.5));
-        ga.bin1 = b1; ga.bin2 = 2u * b1;
+#ifndef PT_BIN1_PCT
+#define PT_BIN1_PCT 75
+#endif
+#ifndef PT_BIN2_PCT
+#define PT_BIN2_PCT 140
+#endif
+        const uint32_t b1 = (uint32_t)std::max(2.0, std::floor(0.01 * PT_BIN1_PCT * navg + 0.5));
+        ga.bin1 = b1; ga.bin2 = std::max(b1 + 1u, (uint32_t)std::floor(0.01 * PT_BIN2_PCT * navg + 0.5));
     }
     ga.ncells = ncells; ga.nrefs = (uint32_t)nrefs; ga.nbig = (uint32_t)bigs.size();
     ga.blob_bytes = (uint32_t)bytes;
