@@ -817,7 +817,7 @@ __host__ __device__ inline uint32_t p_lds_bytes(int G, int M) { return p_queue_o
 #define PT_MESH_TURN 128                 // a MESH turn runs when this many rays wait (or nothing else can run): 64 are popped, the
 #endif                                   //   others are the reserve that lets a thinned-out WALK stop (kMeshMinWalk)
 #ifndef PT_MESH_MIN_WALK
-#define PT_MESH_MIN_WALK 24
+#define PT_MESH_MIN_WALK 16
 #endif
 constexpr uint32_t kMeshTurn = PT_MESH_TURN;
 constexpr uint32_t kMStack = kMeshTurn + 128;   // entries (bound: below kMeshTurn before a push of at most 64; a MESH turn pops 64 and pushes fewer than 64 + 64)
