@@ -599,9 +599,10 @@ int enqueue_iterations(pt_context *c, uint32_t iteration, uint32_t batch, int st
         pa.qscale = c->wide_qscale; pa.slack_max = c->wide_slack;
         pa.tap = c->d_tap; pa.tap_count = c->d_tap_count; pa.tap_level = c->tap_level; pa.tap_cap = c->tap_cap;
         const uint64_t waves = (uint64_t)c->grid_path * (uint64_t)c->path_waves;
-        {   // job size: about 48 jobs per wave of the launch, whole groups, 64 .. kJobMax rays
+        {   // job size: at least 48 jobs per wave of the launch, whole groups, 64 .. kJobMax rays (rounded DOWN: the last jobs a wave
+            // draws decide how long the launch's tail is -- 64 instead of 128 rays at the driver's 20 steps: 0.1691 -> 0.1670 ms/step)
             const uint64_t per_wave = (uint64_t)n_rays / (waves * 48u);
-            uint32_t job = (uint32_t)((per_wave + 63u) & ~63ull);
+            uint32_t job = (uint32_t)(per_wave & ~63ull);
             if (job < 64u) job = 64u;
             if (job > kJobMax) job = kJobMax;
             if (c->cfg.chunk_rays > 0) job = (uint32_t)((c->cfg.chunk_rays + 63) & ~63);      // explicit
