@@ -59,6 +59,7 @@ struct pt_context {
     uint32_t turn_limit = 0;         // whole-path kernels: explicit guard against a wave that never finishes (0 = by launch size; pt_debug_set_turn_limit)
     int occ_bounce = 2;              // resident blocks per CU of the per-bounce kernel in use
     uint32_t lds_path = 0;
+    int path_cap = 144;              //   records per wave of k_path_q (one of kPCaps)
     bool queue_mesh = false;         //   its variant with mesh traversal (scene has MESH primitives with triangles)
     FaceFrame *d_frames = nullptr;   // [G][3] shading frames of the box primitives (k_bounce_q)
     CullRec *d_cull = nullptr;       // bounds for its culling pass, cubes first
@@ -623,7 +624,7 @@ int enqueue_iterations(pt_context *c, uint32_t iteration, uint32_t batch, int st
         {
             Scoped s(c, 1);
             if (c->pathw) wide_launch(c->wide_variant, c->grid_path, c->lds_path, c->stream, a, pa, c->grid, c->d_geoms, c->d_mats, c->d_frames);
-            else path_launch(c->queue_mesh, c->pathq_nee, c->grid_path, c->lds_path, c->stream, a, pa, c->d_geoms, c->d_mats, qt);
+            else path_launch(c->queue_mesh, c->pathq_nee, c->path_cap, c->grid_path, c->lds_path, c->stream, a, pa, c->d_geoms, c->d_mats, qt);
             HIPCHK(hipGetLastError());
         }
         if (batch > 1u || c->nee) { int rc = enqueue_fold(c, batch); if (rc) return rc; }
@@ -1082,14 +1083,22 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     // ordering = 2: whole paths in one launch -- a persistent grid of its own and the waves' level rings
     c->pathq = (c->queue && c->cfg.ordering == 2 && !c->nee && !big_mesh) || c->pathq_nee;       // (a mesh of 2^24 triangles or more: per-bounce kernels)
     if (c->pathq) {
-        c->lds_path = c->queue_mesh ? p_mesh_lds_bytes(G, M) : p_lds_bytes(G, M);
+        // records per wave: the largest instantiated capacity that leaves the occupancy target standing (five blocks per CU, four
+        // with meshes) beside this scene's tables; if none does, the smallest
         int occ = 0;
-        HIPCHK(path_setup(c->queue_mesh, c->pathq_nee, c->lds_path, &occ));
+        const int target = c->queue_mesh ? 4 : 5;
+        for (int cap : kPCaps) {
+            c->path_cap = cap;
+            c->lds_path = c->queue_mesh ? p_mesh_lds_bytes(G, M, (uint32_t)cap) : p_lds_bytes(G, M, (uint32_t)cap);
+            if (c->lds_path > 160u * 1024u) continue;
+            HIPCHK(path_setup(c->queue_mesh, c->pathq_nee, cap, c->lds_path, &occ));
+            if (occ >= target) break;
+        }
         if (c->cfg.blocks_per_cu > 0) occ = c->cfg.blocks_per_cu;
         c->grid_path = c->n_cu * occ;
         c->path_waves = (uint32_t)kWaves;
         const size_t extra = c->pathq_nee ? kNeeExtraFields : 0;
-        c->arena_bytes = (size_t)c->grid_path * kWaves * (((size_t)kSFields + extra) * (kStack + (c->queue_mesh ? kMStack : 0u)) + ((size_t)kPParked + extra) * kPCap +
+        c->arena_bytes = (size_t)c->grid_path * kWaves * (((size_t)kSFields + extra) * (kStack + (c->queue_mesh ? kMStack : 0u)) + ((size_t)kPParked + extra) * (size_t)c->path_cap +
                                                            (c->queue_mesh ? (size_t)kMFields * kMStack : 0)) * sizeof(float);
         HIPCHK(hipMalloc(&c->d_arena, c->arena_bytes));
         HIPCHK(hipMalloc(&c->d_tickets, (size_t)kTicketCtrs * kTicketStride * sizeof(uint32_t)));

@@ -12,13 +12,14 @@ namespace ptk {
 // the emitter's radiance is added) does the scattered ray itself go on.  The radiance a path gathers rides with it (`acc`, the
 // oracle's L: emitter hits and shadow-ray contributions summed in bounce order from zero) and is added to the path's pixel of its
 // iteration's accumulator plane once, where the path ends -- the same additions in the same order as the per-bounce kernels.
-template <bool MESH, bool NEE>
+template <bool MESH, bool NEE, int CAP>
 __global__ __launch_bounds__(kBlock, MESH ? 4 : NEE ? 5 : 6) void k_path_q(SegArgs a, PathArgs pa, const GeomRec *__restrict__ geoms,
                                                       const MatRec *__restrict__ mats, QTables qt) {
     // stack / parked fields of the NEE variant beyond the common ones: acc (3), scattered direction (3), cos at the surface,
     // 1 / pdf of the light sample, squared distance to it.  Level word: level | shadow << 8 | count-emission << 9 | light << 10
     constexpr uint32_t SF = NEE ? kSFields + 9u : kSFields;
     constexpr uint32_t PF = NEE ? kPParked + 9u : kPParked;
+    constexpr uint32_t kPCap = (uint32_t)CAP;               // records per wave (pt_kernels.hpp, kPCaps)
     constexpr uint32_t PX = kPParked;                      // where the NEE words start among a record's parked words
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *ctrl = reinterpret_cast<uint32_t *>(smem);   // [1] emitted (block sum), [32..96] survivors per level
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : NEE ? 5 : 6) void k_path_q(SegAr
         if (ub) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, off * 4u, f * kMStack * 4u, 0);
         else pa.arena[(size_t)off + f * kMStack] = v;
     };
-    unsigned long long *mkey = reinterpret_cast<unsigned long long *>(smem + p_mesh_offset(a.G, a.M) + (MESH ? wave * kMScratchBytes : 0u));
+    unsigned long long *mkey = reinterpret_cast<unsigned long long *>(smem + p_mesh_offset(a.G, a.M, kPCap) + (MESH ? wave * kMScratchBytes : 0u));
     uint32_t *mposn = reinterpret_cast<uint32_t *>(mkey + 64);
     uint32_t *mpair = mposn + 64;
     constexpr unsigned long long kMeshNoHit = (0x7F61B1E6ull << 32) | 0x7FFFFFFFull;      // (3.0e38f, no triangle): mesh_test's initial best
@@ -278,16 +279,10 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : NEE ? 5 : 6) void k_path_q(SegAr
                     float *r = q + pos;
                     r[0 * kPCap] = o.x; r[1 * kPCap] = o.y; r[2 * kPCap] = o.z;
                     r[3 * kPCap] = d.x; r[4 * kPCap] = d.y; r[5 * kPCap] = d.z;
-#if PT_P_SPLIT
-                    park_st(pos, 0, thr.x); park_st(pos, 1, thr.y); park_st(pos, 2, thr.z); park_st(pos, 3, __uint_as_float(pv));
-                    r[6 * kPCap] = __uint_as_float(mask);
-                    r[7 * kPCap] = __uint_as_float(next_j | (level << 8));
-#else
                     r[6 * kPCap] = thr.x; r[7 * kPCap] = thr.y; r[8 * kPCap] = thr.z;
                     r[9 * kPCap] = __uint_as_float(pv);
                     r[10 * kPCap] = __uint_as_float(mask);
                     r[11 * kPCap] = __uint_as_float(next_j | (level << 8));
-#endif
                     if constexpr (NEE) {
                         park_st(pos, PX + 0, acc.x); park_st(pos, PX + 1, acc.y); park_st(pos, PX + 2, acc.z);
                         park_st(pos, PX + 3, nd.x); park_st(pos, PX + 4, nd.y); park_st(pos, PX + 5, nd.z);
@@ -507,7 +502,7 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : NEE ? 5 : 6) void k_path_q(SegAr
         qstat(isb ? 10 : 12, 1ull); qstat(isb ? 11 : 13, (unsigned long long)cnt);
 #endif
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (PT_P_SPLIT || NEE) {
+        if (NEE) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, PT_SELF_SCOPE);            // the parked words of earlier groups have landed (vmcnt 0) ...
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, PT_SELF_SCOPE);            // ... before they are read back through the same L1
         }
@@ -515,18 +510,10 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : NEE ? 5 : 6) void k_path_q(SegAr
             const float *r = q + pos;
             o = mk(r[0 * kPCap], r[1 * kPCap], r[2 * kPCap]);
             d = mk(r[3 * kPCap], r[4 * kPCap], r[5 * kPCap]);
-#if PT_P_SPLIT
-            // throughput and pixel word: requested now, used after the test
-            thr = mk(park_ld(pos, 0), park_ld(pos, 1), park_ld(pos, 2));
-            pv = __float_as_uint(park_ld(pos, 3));
-            mask = __float_as_uint(r[6 * kPCap]);
-            const uint32_t jl = __float_as_uint(r[7 * kPCap]);
-#else
             thr = mk(r[6 * kPCap], r[7 * kPCap], r[8 * kPCap]);
             pv = __float_as_uint(r[9 * kPCap]);
             mask = __float_as_uint(r[10 * kPCap]);
             const uint32_t jl = __float_as_uint(r[11 * kPCap]);
-#endif
             if constexpr (NEE) {
                 acc = mk(park_ld(pos, PX + 0), park_ld(pos, PX + 1), park_ld(pos, PX + 2));
                 nd = mk(park_ld(pos, PX + 3), park_ld(pos, PX + 4), park_ld(pos, PX + 5));
@@ -780,9 +767,23 @@ __global__ __launch_bounds__(kBlock, MESH ? 4 : NEE ? 5 : 6) void k_path_q(SegAr
 }
 
 // ------------------------------------------------------------------ host side ---------
-hipError_t path_setup(bool mesh, bool nee, uint32_t lds_bytes, int *blocks_per_cu) {
-    const void *fn = nee ? reinterpret_cast<const void *>(&k_path_q<false, true>)
-                         : mesh ? reinterpret_cast<const void *>(&k_path_q<true, false>) : reinterpret_cast<const void *>(&k_path_q<false, false>);
+template <int CAP>
+static const void *path_fn(bool mesh, bool nee) {
+    return nee ? reinterpret_cast<const void *>(&k_path_q<false, true, CAP>)
+               : mesh ? reinterpret_cast<const void *>(&k_path_q<true, false, CAP>) : reinterpret_cast<const void *>(&k_path_q<false, false, CAP>);
+}
+template <int CAP>
+static void path_go(bool mesh, bool nee, int grid, uint32_t lds, hipStream_t st, const SegArgs &a, const PathArgs &pa,
+                    const GeomRec *g, const MatRec *m, const QTables &qt) {
+    if (nee) hipLaunchKernelGGL((k_path_q<false, true, CAP>), dim3(grid), dim3(kBlock), lds, st, a, pa, g, m, qt);
+    else if (mesh) hipLaunchKernelGGL((k_path_q<true, false, CAP>), dim3(grid), dim3(kBlock), lds, st, a, pa, g, m, qt);
+    else hipLaunchKernelGGL((k_path_q<false, false, CAP>), dim3(grid), dim3(kBlock), lds, st, a, pa, g, m, qt);
+}
+
+hipError_t path_setup(bool mesh, bool nee, int cap, uint32_t lds_bytes, int *blocks_per_cu) {
+    const void *fn = cap == 160 ? path_fn<160>(mesh, nee) : cap == 144 ? path_fn<144>(mesh, nee) : cap == 128 ? path_fn<128>(mesh, nee)
+                   : cap == 112 ? path_fn<112>(mesh, nee) : cap == 96 ? path_fn<96>(mesh, nee) : cap == 80 ? path_fn<80>(mesh, nee) : nullptr;
+    if (!fn) return hipErrorInvalidValue;
     if (lds_bytes > 64u * 1024u) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -793,11 +794,16 @@ hipError_t path_setup(bool mesh, bool nee, uint32_t lds_bytes, int *blocks_per_c
     return hipSuccess;
 }
 
-void path_launch(bool mesh, bool nee, int grid, uint32_t lds, hipStream_t st, const SegArgs &a, const PathArgs &pa,
+void path_launch(bool mesh, bool nee, int cap, int grid, uint32_t lds, hipStream_t st, const SegArgs &a, const PathArgs &pa,
                  const GeomRec *g, const MatRec *m, const QTables &qt) {
-    if (nee) hipLaunchKernelGGL((k_path_q<false, true>), dim3(grid), dim3(kBlock), lds, st, a, pa, g, m, qt);
-    else if (mesh) hipLaunchKernelGGL((k_path_q<true, false>), dim3(grid), dim3(kBlock), lds, st, a, pa, g, m, qt);
-    else hipLaunchKernelGGL((k_path_q<false, false>), dim3(grid), dim3(kBlock), lds, st, a, pa, g, m, qt);
+    switch (cap) {
+    case 160: path_go<160>(mesh, nee, grid, lds, st, a, pa, g, m, qt); break;
+    case 144: path_go<144>(mesh, nee, grid, lds, st, a, pa, g, m, qt); break;
+    case 128: path_go<128>(mesh, nee, grid, lds, st, a, pa, g, m, qt); break;
+    case 112: path_go<112>(mesh, nee, grid, lds, st, a, pa, g, m, qt); break;
+    case 96: path_go<96>(mesh, nee, grid, lds, st, a, pa, g, m, qt); break;
+    default: path_go<80>(mesh, nee, grid, lds, st, a, pa, g, m, qt); break;
+    }
 }
 
 #ifdef PT_CULL_STATS

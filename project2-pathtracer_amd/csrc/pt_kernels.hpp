@@ -638,21 +638,18 @@ struct QTables {
 //     holds more than 63 + 2 x 64 rays), else a group of camera rays, else whatever is left.
 // No barrier, no inter-wave traffic, no pool; per-level live counts through one LDS atomic per group.  Results: the same image, live
 // counts and emitter hits as every other kernel (the rays of a bounce are a set, not a sequence).
-#ifndef PT_P_SPLIT
-#define PT_P_SPLIT 0                     // 1 (experiment, measured 29 % slower: DESIGN.md appendix): a queue record keeps what the exact test reads
-#endif                                   //    (origin, direction, mask, candidate | level: 8 dwords) in LDS and parks throughput + pixel word in the wave's
-                                         //    arena in global memory: 168 records per wave at six blocks per CU where 12-dword records give 138 at five
-#ifndef PT_P_CAP
-#define PT_P_CAP (PT_P_SPLIT ? 168 : 138)  // records per wave
-#endif
-constexpr uint32_t kPCap = PT_P_CAP;
-constexpr uint32_t kPFields = PT_P_SPLIT ? 8 : 12;   // ox oy oz dx dy dz [tx ty tz pixelword] mask candidate|level<<8
-constexpr uint32_t kPParked = PT_P_SPLIT ? 4 : 0;    // tx ty tz pixelword per record, in the arena behind the wave's stack
+// Records per wave: as many as leave the kernel's occupancy target standing (five blocks per CU; four with meshes) next to the
+// scene's tables -- 144 on the Cornell box (138 measured 1.5 % slower, 146 costs the fifth block: 0.2078 vs 0.1656 ms/step).
+// The kernel is instantiated for a few capacities; pt_upload_scene takes the largest that fits (path_pick_cap).
+constexpr int kPCaps[] = {160, 144, 128, 112, 96, 80};
+constexpr uint32_t kPCapMax = 160;
+constexpr uint32_t kPFields = 12;        // ox oy oz dx dy dz tx ty tz pixelword mask candidate|level<<8
+constexpr uint32_t kPParked = 0;         // (words of a record parked in the arena behind the wave's stack: the NEE variant adds its own)
 #ifndef PT_STACK_SLOTS
 #define PT_STACK_SLOTS 256               // a smaller value is a test build: it provokes the overflow guard (tests/test_gpu_round3.py)
 #endif
 constexpr uint32_t kStack = PT_STACK_SLOTS;   // rays on a wave's stack.  Bound = the wave's whole population: camera rays only enter while the stack holds
-                                              //   fewer than 64 rays and the queues at most kPCap - 64 records: 63 + 74 + 64 = 201 rays in all, wherever they
+                                              //   fewer than 64 rays and the queues at most cap - 64 records: 63 + 96 + 64 = 223 rays in all at most, wherever they
                                               //   sit later (k_path_q<MESH>: + the kMStack rays of the mesh stack, so its stack is that much deeper)
 constexpr uint32_t kSFields = 11;        // ox oy oz dx dy dz tx ty tz pixelword level
 constexpr uint32_t kTicketCtrs = 16, kTicketStride = 64;
@@ -804,7 +801,7 @@ __host__ __device__ __forceinline__ bool grid_walk_sane(const GridArgs &ga, f3 o
 
 __host__ __device__ inline uint32_t p_cursor_offset(int G, int M) { return q_lds_offset(G, M); }
 __host__ __device__ inline uint32_t p_queue_offset(int G, int M) { return p_cursor_offset(G, M); }
-__host__ __device__ inline uint32_t p_lds_bytes(int G, int M) { return p_queue_offset(G, M) + (uint32_t)kWaves * kPCap * kPFields * 4u; }
+__host__ __device__ inline uint32_t p_lds_bytes(int G, int M, uint32_t cap) { return p_queue_offset(G, M) + (uint32_t)kWaves * cap * kPFields * 4u; }
 
 // k_path_q<MESH>: rays whose next candidate is a MESH primitive wait on a third typed stack, in the wave's arena behind the
 // parked words (field f of entry s at moff + f * kMStack + s): the ray's whole test state -- what a queue record holds, the
@@ -830,8 +827,8 @@ constexpr uint32_t kMPairs = 64u + 64u * kMeshWalkSteps;     // (ray, triangle) 
 constexpr uint32_t kMScratchBytes = 64u * 8u + 64u * 4u + kMPairs * 4u;     // keys, positions, pairs
 constexpr uint32_t kMeshMinWalk = PT_MESH_MIN_WALK;   // a WALK below this many lanes stops while other rays wait: its rays go back with their cursors
 constexpr int kMeshPairTris = 1 << 24;   // a pair entry holds lane (6 bits), triangles left in the leaf (2), triangle (24)
-__host__ __device__ inline uint32_t p_mesh_offset(int G, int M) { return (p_lds_bytes(G, M) + 15u) & ~15u; }
-__host__ __device__ inline uint32_t p_mesh_lds_bytes(int G, int M) { return p_mesh_offset(G, M) + (uint32_t)kWaves * kMScratchBytes; }
+__host__ __device__ inline uint32_t p_mesh_offset(int G, int M, uint32_t cap) { return (p_lds_bytes(G, M, cap) + 15u) & ~15u; }
+__host__ __device__ inline uint32_t p_mesh_lds_bytes(int G, int M, uint32_t cap) { return p_mesh_offset(G, M, cap) + (uint32_t)kWaves * kMScratchBytes; }
 
 
 struct FoldArgs {
@@ -868,8 +865,8 @@ hipError_t queue_setup(bool mesh, uint32_t lds_bytes, int *blocks_per_cu);
 void queue_launch(bool mesh, bool last, bool gen, int grid, uint32_t lds_bytes, hipStream_t stream, const SegArgs &a,
                   const GeomRec *geoms, const MatRec *mats, const QTables &qt);
 
-hipError_t path_setup(bool mesh, bool nee, uint32_t lds_bytes, int *blocks_per_cu);
-void path_launch(bool mesh, bool nee, int grid, uint32_t lds_bytes, hipStream_t stream, const SegArgs &a, const PathArgs &pa,
+hipError_t path_setup(bool mesh, bool nee, int cap, uint32_t lds_bytes, int *blocks_per_cu);
+void path_launch(bool mesh, bool nee, int cap, int grid, uint32_t lds_bytes, hipStream_t stream, const SegArgs &a, const PathArgs &pa,
                  const GeomRec *geoms, const MatRec *mats, const QTables &qt);
 constexpr uint32_t kNeeExtraFields = 9;  // k_path_q<NEE>: words a stack / parked record holds beyond the common ones
 
