@@ -299,9 +299,9 @@ def main():
 
     # S streams per GPU (pt_config.streams): the context shards this rank's rows once more over S internal contexts,
     # each on its own HIP stream, all rendering straight into the same device accumulator.
-    # (k_path_w, scenes of 33..256 primitives, fills every CU's LDS with one block: a second context cannot run beside it)
-    wide = args.ordering == 2 and 32 < len(geoms) <= 256 and not args.direct_light and not sf.meshes()
-    S = args.streams if args.streams > 0 else (2 if (W * H // world) * args.steps >= 30_000_000 and not wide else 1)
+    # (k_path_w, scenes of 33..256 primitives, fills every CU's LDS with one block, so a second context's blocks only start where
+    # the first one's have finished -- which is what hides the first launch's drain: configs[3] 0.948 -> 0.932 ms/step with two)
+    S = args.streams if args.streams > 0 else (2 if (W * H // world) * args.steps >= 30_000_000 else 1)
     accum = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda:%d" % device)
     tracer = pkg.PathTracer(pkg.default_config(device=device, max_depth=depth, row_offset=rank, row_stride=world, streams=S,
                                                chunk_rays=args.chunk_rays, blocks_per_cu=args.blocks_per_cu, culling=args.culling, batch=args.batch,
