@@ -522,6 +522,7 @@ def main():
                        "compaction": "wave-autonomous (ballot + mbcnt ranks); " + {0: "stable order, one launch per bounce (ordering=0)", 1: "typed work queues, one launch per bounce (ordering=1)", 2: "whole paths, one launch per group (ordering=2)"}.get(args.ordering, "stable order"),
                        "primitives": nprims,
                        "direct_light": bool(args.direct_light), "streams_per_gpu": S,
+                       "kernel_shape": (tracer.path_shape() if hasattr(tracer, "path_shape") and hasattr(pkg.lib(), "pt_debug_path_shape") else None),
                        "warmup_passes": "W steps + %d untimed K-step passes (same launch-group shape as the timed passes; until three in a row agree to 1 %%)" % warm_passes},
             "roofline": roof,
         }

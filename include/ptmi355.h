@@ -238,6 +238,11 @@ int  pt_debug_trace_pool(pt_context *ctx, int iteration, int bounces, int *count
  * PT_ERR_HIP ("turn limit reached") at the next pt_sync instead of hanging the device.  0 = sized by the launch (default);
  * tests lower it to provoke the guard. */
 int  pt_debug_set_turn_limit(pt_context *ctx, unsigned int turns);
+/* How the uploaded scene runs on the whole-path kernels (ordering = 2): out[0] = kernel family (0 none: per-bounce kernels,
+ * 1 k_path_q, 2 k_path_w), out[1] = waves per block, out[2] = blocks per CU, out[3] = LDS bytes per block, out[4] = queue
+ * records (k_path_q) or ray slots (k_path_w) per wave, out[5] = arena bytes, out[6] = 1 with meshes, out[7] = 1 with direct
+ * light.  A context with streams > 1 reports its first internal context. */
+int  pt_debug_path_shape(pt_context *ctx, unsigned int *out8);
 /* generateRandomNumberFromThread (src/raytraceKernel.cu:30-37) evaluated on the device for n
  * (x,y) pairs. */
 int  pt_debug_rng_from_thread(pt_context *ctx, float resx, float resy, float time, int n,

@@ -109,6 +109,8 @@ def lib():
     L.pt_debug_hemisphere.argtypes = [vp, C.c_int, fp, fp, fp]
     L.pt_debug_sincos.argtypes = [vp, C.c_int, fp, fp, fp]
     L.pt_debug_light_points.argtypes = [vp, C.c_int, C.c_int, fp, fp]
+    if hasattr(L, "pt_debug_path_shape"):
+        L.pt_debug_path_shape.argtypes = [vp, C.POINTER(C.c_uint)]
     if hasattr(L, "pt_debug_grid_probe"):      # (absent from builds of older commits that tools/ab_lib.sh compares against)
         L.pt_debug_grid_probe.argtypes = [C.POINTER(Geom), C.c_int, C.c_int, fp, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.pt_scene_load.argtypes = [C.c_char_p, C.POINTER(vp)]
@@ -128,7 +130,7 @@ EXPORTS = [
     "pt_abi_version", "pt_last_error", "pt_config_default", "pt_device_count", "pt_create", "pt_destroy",
     "pt_upload_scene", "pt_set_meshes", "pt_scene_mesh_count", "pt_scene_mesh", "pt_set_image", "pt_bind_device_image", "pt_get_image", "pt_get_rows", "pt_gather_rows_peer", "pt_render", "pt_sync",
     "pt_display", "pt_set_profiling", "pt_get_stats", "pt_reset_stats", "pt_get_resolution", "pt_debug_primary_hits",
-    "pt_debug_trace_pool", "pt_debug_set_turn_limit", "pt_debug_rng_from_thread", "pt_debug_hemisphere", "pt_debug_sincos", "pt_debug_light_points", "pt_debug_grid_probe",
+    "pt_debug_trace_pool", "pt_debug_set_turn_limit", "pt_debug_path_shape", "pt_debug_rng_from_thread", "pt_debug_hemisphere", "pt_debug_sincos", "pt_debug_light_points", "pt_debug_grid_probe",
     "pt_scene_load", "pt_scene_free", "pt_scene_counts", "pt_scene_image_name", "pt_scene_flatten",
     "pt_scene_object_matrices", "pt_build_transform", "pt_image_to_u8", "pt_image_save",
 ]
@@ -294,6 +296,13 @@ class PathTracer:
         _check(lib().pt_debug_trace_pool(self._h, iteration, bounces, C.byref(cnt), *[_fp(a) for a in arrs],
                                          pix.ctypes.data_as(C.POINTER(C.c_uint32))))
         return cnt.value, [a[:cnt.value] for a in arrs], pix[:cnt.value]
+
+    def path_shape(self):
+        """how the uploaded scene runs on the whole-path kernels (pt_debug_path_shape)"""
+        out = (C.c_uint * 8)()
+        _check(lib().pt_debug_path_shape(self._h, out))
+        return dict(family=("per-bounce", "k_path_q", "k_path_w")[out[0]], waves_per_block=out[1], blocks_per_cu=out[2], lds_bytes=out[3],
+                    records_per_wave=out[4], arena_bytes=out[5], meshes=bool(out[6]), direct_light=bool(out[7]))
 
     def set_turn_limit(self, turns):
         _check(lib().pt_debug_set_turn_limit(self._h, int(turns)))

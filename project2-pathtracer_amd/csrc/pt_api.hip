@@ -1568,6 +1568,22 @@ int pt_debug_trace_pool(pt_context *c, int iteration, int bounces, int *count, f
     return check_device_error(c);
 }
 
+int pt_debug_path_shape(pt_context *c, unsigned int *out8) {
+    if (!c || !out8) { pth::set_error("pt_debug_path_shape: bad argument"); return PT_ERR_ARGUMENT; }
+    if (!c->subs.empty()) return pt_debug_path_shape(c->subs[0], out8);
+    if (!c->scene_ready) { pth::set_error("pt_debug_path_shape: no scene uploaded"); return PT_ERR_STATE; }
+    const unsigned int blocks = c->n_cu > 0 ? (unsigned int)(c->grid_path / c->n_cu) : 0u;
+    out8[0] = c->pathw ? 2u : c->pathq ? 1u : 0u;
+    out8[1] = (c->pathq || c->pathw) ? c->path_waves : 0u;
+    out8[2] = (c->pathq || c->pathw) ? blocks : 0u;
+    out8[3] = (c->pathq || c->pathw) ? c->lds_path : 0u;
+    out8[4] = c->pathw ? c->wide_slots : c->pathq ? (unsigned int)c->path_cap : 0u;
+    out8[5] = (unsigned int)(c->arena_bytes < 0xFFFFFFFFull ? c->arena_bytes : 0xFFFFFFFFull);
+    out8[6] = c->queue_mesh ? 1u : 0u;
+    out8[7] = c->pathq_nee ? 1u : 0u;
+    return PT_OK;
+}
+
 int pt_debug_set_turn_limit(pt_context *c, unsigned int turns) {
     if (!c) { pth::set_error("pt_debug_set_turn_limit: null context"); return PT_ERR_ARGUMENT; }
     c->turn_limit = turns;

@@ -205,3 +205,29 @@ def test_bench_more_ranks_gloo_rehearsal_frames_match_the_oracle(pt, ranks, work
     want, _ = orc.render(orc.load_golden_scene(scene).with_resolution(w, h), oracle_config(8), 3, 4)
     assert got.shape == want.shape and np.array_equal(got, want)
 
+
+def test_whole_path_kernel_shape_follows_the_scene(pt):
+    """pt_upload_scene sizes the whole-path kernels to the scene: k_path_q takes the largest instantiated queue capacity that still
+    leaves five blocks per CU beside the scene's tables (four with meshes), k_path_w one block per CU of as many waves as fit --
+    reported by pt_debug_path_shape (and in bench.py's config)."""
+    def shape(name, keep=None, **kw):
+        sc = orc.load_golden_scene(name).with_resolution(64, 48)
+        if keep is not None:
+            sc = orc.Scene(sc.geoms[:keep], sc.materials, sc.camera)
+        tr = make_tracer(sc, depth=4, **kw)
+        out = tr.path_shape()
+        tr.close()
+        return out
+    a = shape("cornell_mirror", ordering=2)
+    assert a["family"] == "k_path_q" and a["blocks_per_cu"] == 5 and a["records_per_wave"] == 144 and a["waves_per_block"] == 4
+    assert 5 * a["lds_bytes"] <= 160 * 1024 < 5 * (a["lds_bytes"] + 4 * 16 * 48)          # sixteen records more would cost the fifth block
+    b = shape("random256", keep=32, ordering=2)                                               # 32 primitives: bigger tables, fewer records, still five blocks
+    assert b["family"] == "k_path_q" and b["blocks_per_cu"] == 5 and b["records_per_wave"] < 144
+    c = shape("random256", ordering=2)
+    assert c["family"] == "k_path_w" and c["blocks_per_cu"] == 1 and c["waves_per_block"] == 16 and c["records_per_wave"] == 112
+    d = shape("cornell_mesh", ordering=2)
+    assert d["family"] == "k_path_q" and d["meshes"] and d["blocks_per_cu"] == 4
+    e = shape("cornell_mirror", ordering=2, direct_light=1)
+    assert e["family"] == "k_path_q" and e["direct_light"] and e["blocks_per_cu"] == 5
+    assert shape("cornell_mirror", ordering=0)["family"] == "per-bounce"
+
