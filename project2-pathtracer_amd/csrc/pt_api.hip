@@ -1083,10 +1083,10 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     // ordering = 2: whole paths in one launch -- a persistent grid of its own and the waves' level rings
     c->pathq = (c->queue && c->cfg.ordering == 2 && !c->nee && !big_mesh) || c->pathq_nee;       // (a mesh of 2^24 triangles or more: per-bounce kernels)
     if (c->pathq) {
-        // records per wave: the largest instantiated capacity that leaves the occupancy target standing (five blocks per CU, four
-        // with meshes) beside this scene's tables; if none does, the smallest
+        // records per wave: the largest instantiated capacity that leaves the occupancy target standing (five blocks per CU) beside
+        // this scene's tables (and the scratch of the mesh stages); if none does, the smallest
         int occ = 0;
-        const int target = c->queue_mesh ? 4 : 5;
+        const int target = 5;
         for (int cap : kPCaps) {
             c->path_cap = cap;
             c->lds_path = c->queue_mesh ? p_mesh_lds_bytes(G, M, (uint32_t)cap) : p_lds_bytes(G, M, (uint32_t)cap);

@@ -13,7 +13,7 @@ namespace ptk {
 // oracle's L: emitter hits and shadow-ray contributions summed in bounce order from zero) and is added to the path's pixel of its
 // iteration's accumulator plane once, where the path ends -- the same additions in the same order as the per-bounce kernels.
 template <bool MESH, bool NEE, int CAP>
-__global__ __launch_bounds__(kBlock, MESH ? 4 : NEE ? 5 : 6) void k_path_q(SegArgs a, PathArgs pa, const GeomRec *__restrict__ geoms,
+__global__ __launch_bounds__(kBlock, (MESH || NEE) ? 5 : 6) void k_path_q(SegArgs a, PathArgs pa, const GeomRec *__restrict__ geoms,
                                                       const MatRec *__restrict__ mats, QTables qt) {
     // stack / parked fields of the NEE variant beyond the common ones: acc (3), scattered direction (3), cos at the surface,
     // 1 / pdf of the light sample, squared distance to it.  Level word: level | shadow << 8 | count-emission << 9 | light << 10

@@ -638,7 +638,7 @@ struct QTables {
 //     holds more than 63 + 2 x 64 rays), else a group of camera rays, else whatever is left.
 // No barrier, no inter-wave traffic, no pool; per-level live counts through one LDS atomic per group.  Results: the same image, live
 // counts and emitter hits as every other kernel (the rays of a bounce are a set, not a sequence).
-// Records per wave: as many as leave the kernel's occupancy target standing (five blocks per CU; four with meshes) next to the
+// Records per wave: as many as leave the kernel's occupancy target standing (five blocks per CU) next to the
 // scene's tables -- 144 on the Cornell box (138 measured 1.5 % slower, 146 costs the fifth block: 0.2078 vs 0.1656 ms/step).
 // The kernel is instantiated for a few capacities; pt_upload_scene takes the largest that fits (path_pick_cap).
 constexpr int kPCaps[] = {160, 144, 128, 112, 96, 80};
