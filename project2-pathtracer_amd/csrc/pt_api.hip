@@ -1092,6 +1092,10 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
             c->lds_path = c->queue_mesh ? p_mesh_lds_bytes(G, M, (uint32_t)cap) : p_lds_bytes(G, M, (uint32_t)cap);
             if (c->lds_path > 160u * 1024u) continue;
             HIPCHK(path_setup(c->queue_mesh, c->pathq_nee, cap, c->lds_path, &occ));
+            // LDS is handed out in granules of 1 280 bytes (160 KB / 128): the occupancy query does not round, the hardware does --
+            // 32 640 bytes per block were reported as five blocks per CU and ran as four (0.754 vs 0.591 ms/step on the mesh scene)
+            const uint32_t granules = (c->lds_path + 1279u) / 1280u;
+            if (occ >= target && (uint32_t)target * granules * 1280u > 160u * 1024u) occ = target - 1;
             if (occ >= target) break;
         }
         if (c->cfg.blocks_per_cu > 0) occ = c->cfg.blocks_per_cu;
