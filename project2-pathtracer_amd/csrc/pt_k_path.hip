@@ -781,8 +781,10 @@ static void path_go(bool mesh, bool nee, int grid, uint32_t lds, hipStream_t st,
 }
 
 hipError_t path_setup(bool mesh, bool nee, int cap, uint32_t lds_bytes, int *blocks_per_cu) {
-    const void *fn = cap == 160 ? path_fn<160>(mesh, nee) : cap == 144 ? path_fn<144>(mesh, nee) : cap == 128 ? path_fn<128>(mesh, nee)
-                   : cap == 112 ? path_fn<112>(mesh, nee) : cap == 96 ? path_fn<96>(mesh, nee) : cap == 80 ? path_fn<80>(mesh, nee) : nullptr;
+    const void *fn = nullptr;
+#define PT_X(C) if (cap == C) fn = path_fn<C>(mesh, nee);
+    PT_PATH_CAPS(PT_X)
+#undef PT_X
     if (!fn) return hipErrorInvalidValue;
     if (lds_bytes > 64u * 1024u) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -797,12 +799,10 @@ hipError_t path_setup(bool mesh, bool nee, int cap, uint32_t lds_bytes, int *blo
 void path_launch(bool mesh, bool nee, int cap, int grid, uint32_t lds, hipStream_t st, const SegArgs &a, const PathArgs &pa,
                  const GeomRec *g, const MatRec *m, const QTables &qt) {
     switch (cap) {
-    case 160: path_go<160>(mesh, nee, grid, lds, st, a, pa, g, m, qt); break;
-    case 144: path_go<144>(mesh, nee, grid, lds, st, a, pa, g, m, qt); break;
-    case 128: path_go<128>(mesh, nee, grid, lds, st, a, pa, g, m, qt); break;
-    case 112: path_go<112>(mesh, nee, grid, lds, st, a, pa, g, m, qt); break;
-    case 96: path_go<96>(mesh, nee, grid, lds, st, a, pa, g, m, qt); break;
-    default: path_go<80>(mesh, nee, grid, lds, st, a, pa, g, m, qt); break;
+#define PT_X(C) case C: path_go<C>(mesh, nee, grid, lds, st, a, pa, g, m, qt); break;
+    PT_PATH_CAPS(PT_X)
+#undef PT_X
+    default: break;                                        // (path_setup has refused any other capacity)
     }
 }
 

@@ -641,7 +641,8 @@ struct QTables {
 // Records per wave: as many as leave the kernel's occupancy target standing (five blocks per CU) next to the
 // scene's tables -- 144 on the Cornell box (138 measured 1.5 % slower, 146 costs the fifth block: 0.2078 vs 0.1656 ms/step).
 // The kernel is instantiated for a few capacities; pt_upload_scene takes the largest that fits (path_pick_cap).
-constexpr int kPCaps[] = {160, 144, 128, 112, 96, 80};
+#define PT_PATH_CAPS(X) X(160) X(152) X(144) X(136) X(128) X(120) X(112) X(104) X(96) X(88) X(80)
+constexpr int kPCaps[] = {160, 152, 144, 136, 128, 120, 112, 104, 96, 88, 80};
 constexpr uint32_t kPCapMax = 160;
 constexpr uint32_t kPFields = 12;        // ox oy oz dx dy dz tx ty tz pixelword mask candidate|level<<8
 constexpr uint32_t kPParked = 0;         // (words of a record parked in the arena behind the wave's stack: the NEE variant adds its own)
