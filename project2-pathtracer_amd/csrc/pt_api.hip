@@ -1002,9 +1002,14 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         // iterations per launch group: explicit, or enough to put ~32 M rays into a launch (bigger
         // launches amortise the tail of the static schedule; essential when the frame is sharded over
         // GPUs).  The pool's pixel word keeps the slot in its top 8 bits.
+        // (will the scene run on the whole-path kernels?  they keep no ray pools: a launch group may be bigger, and the pools below
+        // only serve the one-iteration parity hooks)
+        const bool whole_path = c->cfg.ordering == 2 && c->cfg.mode == 0 &&
+                                (c->pathw || (c->queue && !c->nee && !big_mesh) || (c->nee && c->cull && G <= 32 && !have_mesh));
         uint32_t K = 1;
         if (c->cfg.mode == 0 && !big_frame) {
             if (c->cfg.batch > 0) K = (uint32_t)c->cfg.batch;
+            else if (whole_path) K = (uint32_t)((96u * 1024u * 1024u) / n_own);     // configs[4] (4K): 20 iterations per launch 0.925, 10: 0.929, 4: 0.952 ms/step
             else K = (uint32_t)((32u * 1024u * 1024u) / n_own);      // 16 at 1080p: measured best (14: +4 %, 18: +8 % time)
             // the slot field has 7 bits beside the count-emission flag; a plane holds the owned pixels: <= 4 GiB in all
             const uint64_t plane_bytes = (uint64_t)n_own * 3 * sizeof(float);
@@ -1014,7 +1019,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
             if (K < 1u) K = 1u;
         }
         c->batch_max = K;
-        const uint32_t max_rays = K * n_own;
+        const uint32_t max_rays = (whole_path ? 1u : K) * n_own;
         c->nseg = (max_rays + S - 1) / S;                 // S here = the smallest segment size in use
         c->cap = max_rays + 2u * 4096u;
         if (K > 1u || c->nee) {
@@ -1265,8 +1270,10 @@ int pt_render(pt_context *c, int first_iteration, int count) {
             HIPCHK(hipGetLastError());
             c->iterations++;
         } else {
-            uint32_t b = (uint32_t)(first_iteration + count - it);
-            if (b > c->batch_max) b = c->batch_max;
+            // launch groups of about equal size (a short last group would pay a whole launch's tail for a few iterations)
+            const uint32_t rem = (uint32_t)(first_iteration + count - it);
+            const uint32_t groups = (rem + c->batch_max - 1u) / c->batch_max;
+            uint32_t b = (rem + groups - 1u) / groups;
             int rc = enqueue_iterations(c, (uint32_t)it, b, -1);
             if (rc) return rc;
             c->iterations += b;
