@@ -285,12 +285,19 @@ def main():
         import tempfile
         w_, h_ = args.resolution.lower().split("x")
         text = re.sub(r"RES\s+\d+\s+\d+", "RES         %d %d" % (int(w_), int(h_)), open(scene_file).read())
-        # beside the original, so that relative `*.obj` names still resolve
-        tmp = tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False, dir=os.path.dirname(scene_file), prefix=".bench_r%d_" % int(os.environ.get("RANK", "0")))
-        tmp.write(text); tmp.close()
-        scene_file = tmp.name
+        # in a directory of its own (removed at exit) that mirrors the original's sub-directories, so that relative `*.obj`
+        # names still resolve and nothing is written into scenes/
         import atexit
-        atexit.register(lambda f=tmp.name: os.path.exists(f) and os.remove(f))
+        import shutil
+        tmpdir = tempfile.mkdtemp(prefix="ptbench_r%d_" % int(os.environ.get("RANK", "0")))
+        atexit.register(shutil.rmtree, tmpdir, True)
+        src_dir = os.path.dirname(scene_file)
+        for entry in os.listdir(src_dir):
+            if os.path.isdir(os.path.join(src_dir, entry)):
+                os.symlink(os.path.join(src_dir, entry), os.path.join(tmpdir, entry))
+        scene_file = os.path.join(tmpdir, os.path.basename(scene_file))
+        with open(scene_file, "w") as fh:
+            fh.write(text)
         if args.workload not in WORKLOAD_RESOLUTION:
             desc += " [RES overridden to %s]" % args.resolution
     sf = pkg.SceneFile(scene_file)
@@ -486,9 +493,11 @@ def main():
         # `bound`: what the counters say limits the kernel.  Every kernel of this path tracer is limited by vector-instruction
         # issue (IEEE-exact intersection arithmetic), not by HBM; `frac` stays SURVEY.md 8(d)'s HBM-roofline figure (a work rate in
         # survey-byte units, mostly served from L2 / LDS / registers), the measured HBM bandwidth is `hbm_measured`.
-        bound = "valu-issue"
-        if hbm_measured and valu and hbm_measured["frac_of_peak"] > valu["frac"]:
-            bound = "hbm"
+        # Without a counter record of THESE kernel sources (traffic_source.stale, or no record for the workload) the line claims no
+        # limiter: "unmeasured".
+        bound = "unmeasured"
+        if hbm_measured and valu:
+            bound = "hbm" if hbm_measured["frac_of_peak"] > valu["frac"] else "valu-issue"
         roof = {"bound": bound, "stated_roofline": "hbm (SURVEY.md 8(d) algorithmic bytes / 8 TB/s): `achieved`, `peak`, `frac` below are in those units",
                 "kernel": kernel,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -613,9 +613,14 @@ int enqueue_iterations(pt_context *c, uint32_t iteration, uint32_t batch, int st
             pa.static_rounds = (uint32_t)(njobs * c->path_static_eighths / 8u / waves);
         }
         {   // a wave that takes far more scheduling turns than its share of the launch can need gives up with error 3 instead of
-            // hanging the device: 64 x (ray-bounce groups per wave) + slack; pt_debug_set_turn_limit overrides (tests)
+            // hanging the device.  The guard only has to bound a broken build, so it is priced at the real worst case: a live
+            // ray-bounce costs one FRESH turn and at most one exact test per candidate primitive (k_path_q: G <= 32 candidates; k_path_w:
+            // the 8 entries of a list, an overflowing ray one confirming test), a turn may serve a single ray, direct light doubles
+            // the records of a bounce -- groups x 64 x (candidates + 2) x (1 or 2), dynamic jobs may give one wave four times its share;
+            // pt_debug_set_turn_limit overrides (tests)
             const uint64_t groups = ((uint64_t)n_rays * (uint64_t)D / 64u) / waves + 1024u;
-            const uint64_t lim = groups * 64u;
+            const uint64_t cand = c->pathw ? 10u : (uint64_t)(c->G < 32 ? c->G : 32) + 2u;
+            const uint64_t lim = groups * 64u * cand * (c->pathq_nee ? 2u : 1u) * 4u;
             pa.turn_limit = c->turn_limit ? c->turn_limit : (lim > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)lim);
         }
         QTables qt;
@@ -906,6 +911,10 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     // with ordering = 2 the whole-path kernel k_path_w renders and this variant serves the parity hooks)
     c->wide = c->cull && c->geom_lds && !c->nee && !c->queue && !have_mesh && c->cfg.mode == 0 && G > 32 && G <= 256;
     c->pathw = c->wide && c->cfg.ordering == 2;                 // (kept when the clusters below do not fit their mask: k_path_w has its own index)
+    // k_path_w's smallest block shape needs 91 136 bytes beside the tables and at least a small grid (1 KB): with several hundred
+    // materials the tables alone leave less -- such a scene stays on the per-bounce kernels (decided HERE: the launch-group size and
+    // the pools below depend on it)
+    if (c->pathw && (int64_t)160 * 1024 - (int64_t)tables_bytes(G, M, true) - 91136 < 1024) c->pathw = false;
     // two-level culling of the many-primitive variant: clusters of <= kClusterSize primitives of one type
     std::vector<unsigned char> cluster_blob;
     c->nbc = c->nsc = 0; c->cluster_bytes = 0;
@@ -1117,7 +1126,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         // ray slots and work stacks in LDS, the survivors' stacks and the slots' payload in one arena per wave
         GridBuild gb;
         // (the smallest block shape of k_path_w leaves 160 KB - tables - 89 KB to the grid)
-        const size_t grid_room = 160u * 1024u - tables_bytes(G, M, true) - 91136u;
+        const size_t grid_room = (size_t)((int64_t)160 * 1024 - (int64_t)tables_bytes(G, M, true) - 91136);      // >= 1 KB: checked where pathw was decided
         build_grid(g, G, c->cfg.grid_density, grid_room < 24u * 1024u ? grid_room : 24u * 1024u, &gb);
         c->grid = gb.ga;
         HIPCHK(hipMalloc(&c->d_grid, gb.blob.size()));
@@ -1501,33 +1510,47 @@ int pt_debug_trace_pool(pt_context *c, int iteration, int bounces, int *count, f
     // ordering = 2: the whole-path kernel itself is probed -- the rays that survive bounce `bounces` - 1 leave through a tap instead
     // of going on (pool 0 = the camera rays and the pool after the last bounce keep the per-bounce kernels: a whole path has neither)
     const bool tapped = (c->pathq || c->pathw) && !c->nee && bounces >= 1 && bounces < c->cfg.max_depth;
+    // whatever happens below, the context gets its image, counter bank, counters and tap state back before this returns
+    auto restore = [&]() {
+        c->image = saved;
+        c->tap_level = 0;
+        c->bank = bank_saved;
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipMemcpy(c->d_sync, &snapshot, sizeof snapshot, hipMemcpyHostToDevice);
+        c->counts_pending = pending;
+        if (scratch) { (void)hipFree(scratch); scratch = nullptr; }
+        if (c->d_tap) { (void)hipFree(c->d_tap); c->d_tap = nullptr; }
+        if (c->d_tap_count) { (void)hipFree(c->d_tap_count); c->d_tap_count = nullptr; }
+    };
     if (tapped) {
-        c->tap_cap = c->n_own; c->tap_level = (uint32_t)bounces;
-        HIPCHK(hipMalloc(&c->d_tap, (size_t)c->tap_cap * 10 * sizeof(float)));
-        HIPCHK(hipMalloc(&c->d_tap_count, sizeof(uint32_t)));
-        HIPCHK(hipMemsetAsync(c->d_tap_count, 0, sizeof(uint32_t), c->stream));
+        c->tap_cap = c->n_own;
+        hipError_t et = hipMalloc(&c->d_tap, (size_t)c->tap_cap * 10 * sizeof(float));
+        if (et == hipSuccess) et = hipMalloc(&c->d_tap_count, sizeof(uint32_t));
+        if (et == hipSuccess) et = hipMemsetAsync(c->d_tap_count, 0, sizeof(uint32_t), c->stream);
+        if (et != hipSuccess) { restore(); HIPCHK(et); }
+        c->tap_level = (uint32_t)bounces;
     }
     c->image = scratch;
     int rc = enqueue_iterations(c, (uint32_t)iteration, 1u, tapped ? -1 : bounces);
     c->image = saved;
     c->tap_level = 0;
-    if (rc) { (void)hipFree(scratch); if (tapped) { (void)hipFree(c->d_tap); (void)hipFree(c->d_tap_count); c->d_tap = nullptr; c->d_tap_count = nullptr; } return rc; }
-    HIPCHK(hipStreamSynchronize(c->stream));
-    (void)hipFree(scratch);
+    if (rc) { restore(); return rc; }
+    {
+        const hipError_t es = hipStreamSynchronize(c->stream);
+        if (es != hipSuccess) { restore(); HIPCHK(es); }
+    }
     if (tapped) {
         uint32_t n = 0;
         std::vector<float> rec((size_t)c->tap_cap * 10);
-        hipError_t e1 = hipMemcpy(&n, c->d_tap_count, sizeof n, hipMemcpyDeviceToHost);
-        hipError_t e2 = hipMemcpy(rec.data(), c->d_tap, rec.size() * sizeof(float), hipMemcpyDeviceToHost);
+        const hipError_t e1 = hipMemcpy(&n, c->d_tap_count, sizeof n, hipMemcpyDeviceToHost);
+        const hipError_t e2 = hipMemcpy(rec.data(), c->d_tap, rec.size() * sizeof(float), hipMemcpyDeviceToHost);
         SyncBlock after;
-        hipError_t e3 = hipMemcpy(&after, c->d_sync, sizeof after, hipMemcpyDeviceToHost);
-        (void)hipFree(c->d_tap); (void)hipFree(c->d_tap_count);
-        c->d_tap = nullptr; c->d_tap_count = nullptr;
-        HIPCHK(e1); HIPCHK(e2); HIPCHK(e3);
+        const hipError_t e3 = hipMemcpy(&after, c->d_sync, sizeof after, hipMemcpyDeviceToHost);
         const uint32_t live = c->bank ? after.counts_b[bounces] : after.counts[bounces];
-        c->bank = bank_saved;
-        HIPCHK(hipMemcpy(c->d_sync, &snapshot, sizeof snapshot, hipMemcpyHostToDevice));
-        c->counts_pending = pending;
+        if (e3 == hipSuccess && after.error) snapshot.error = after.error;   // a guard that fired in the hook's launch stays visible
+        restore();
+        HIPCHK(e1); HIPCHK(e2); HIPCHK(e3);
+        { const int rce = check_device_error(c); if (rce) return rce; }
         if (n > c->tap_cap || n != live) { pth::set_error("pt_debug_trace_pool: the tap holds %u rays, the live counter of bounce %d says %u", n, bounces, live); return PT_ERR_HIP; }
         // the waves met the rays in their own order: generation order = pixel order
         const size_t cap = c->tap_cap;
@@ -1543,12 +1566,12 @@ int pt_debug_trace_pool(pt_context *c, int iteration, int bounces, int *count, f
         return check_device_error(c);
     }
     SyncBlock after;
-    HIPCHK(hipMemcpy(&after, c->d_sync, sizeof after, hipMemcpyDeviceToHost));
+    const hipError_t ea = hipMemcpy(&after, c->d_sync, sizeof after, hipMemcpyDeviceToHost);
     const bool fused = bounces != 0;
-    const uint32_t n = (fused && c->bank) ? after.counts_b[bounces] : after.counts[bounces];
-    c->bank = bank_saved;
-    HIPCHK(hipMemcpy(c->d_sync, &snapshot, sizeof snapshot, hipMemcpyHostToDevice));
-    c->counts_pending = pending;
+    const uint32_t n = ea == hipSuccess ? ((fused && c->bank) ? after.counts_b[bounces] : after.counts[bounces]) : 0u;
+    if (ea == hipSuccess && after.error) snapshot.error = after.error;       // a guard that fired in the hook's launches stays visible
+    restore();
+    HIPCHK(ea);
     if (count) *count = (int)n;
     const float *src = c->pool[bounces & 1];
     float *dst[9] = {ox, oy, oz, dx, dy, dz, tr, tg, tb};

@@ -345,3 +345,25 @@ def trace_pool(scene, cfg, iteration, bounces):
                                C.byref(cfg), iteration, bounces, *[fptr(a) for a in arrs],
                                pix.ctypes.data_as(C.POINTER(C.c_uint32)))
     return cnt, [a[:cnt] for a in arrs], pix[:cnt]
+
+
+def many_primitives_scene(extra, seed=565, w=160, h=90, size=(0.12, 0.5)):
+    """random256's room (five walls + the light) with `extra` small spheres / rotated cubes of its seven materials: the
+    scenes beyond 256 primitives that the reference's type- and count-agnostic loop (raytraceKernel.cu:134-153,192-194)
+    takes like any other.  Transforms are built by the oracle's restatement of buildTransformationMatrix
+    (orc_build_transform, pinned bit for bit on the reference's utilities.cpp by tests/test_oracle_kats.py)."""
+    base = load_golden_scene("random256").with_resolution(w, h)
+    rng = np.random.default_rng(seed)
+    geoms = list(base.geoms[:6])
+    xf, inv = np.zeros(16, np.float32), np.zeros(16, np.float32)
+    for i in range(extra):
+        c = [float(np.float32(v)) for v in (rng.uniform(-4.6, 4.6), rng.uniform(0.4, 9.2), rng.uniform(-4.6, 4.6))]
+        s = float(np.float32(rng.uniform(*size)))
+        rot = [float(np.float32(v)) for v in rng.uniform(0, 360, 3)] if i & 1 else [0.0, 0.0, 0.0]
+        lib().orc_build_transform(vec3(*c), vec3(*rot), vec3(s, s, s), fptr(xf), fptr(inv))
+        g = Geom()
+        g.type, g.materialid = (1 if i & 1 else 0), i % 7
+        for k in range(16):
+            g.transform[k] = float(xf[k]); g.inverseTransform[k] = float(inv[k])
+        geoms.append(g)
+    return Scene(geoms, base.materials, base.camera)

@@ -1,0 +1,61 @@
+"""-m gpu: scenes of MORE than 256 primitives.  The reference's nearest-hit loop takes any `numberOfGeoms`
+(/root/reference/src/raytraceKernel.cu:137-153, cudaMalloc(numberOfGeoms * sizeof(staticGeom)) at :192-194); so must
+every kernel family here: 257 (one beyond the byte ids), 600, and 1 500 primitives (the geometry table no longer fits
+in LDS).  Image, live counts, emitter hits and the ray pool of one bounce, bit-exact against the oracle."""
+import numpy as np
+import pytest
+
+import orc
+from gpu_common import make_tracer, oracle_config
+
+pytestmark = pytest.mark.gpu
+
+_oracle_cache = {}
+
+
+def _oracle(extra, depth, iters):
+    key = (extra, depth, iters)
+    if key not in _oracle_cache:
+        sc = orc.many_primitives_scene(extra)
+        want, live = orc.render(sc, oracle_config(depth), 1, iters)
+        pool = orc.trace_pool(sc, oracle_config(depth), 2, 3)
+        _oracle_cache[key] = (sc, want, live, pool)
+    return _oracle_cache[key]
+
+
+@pytest.mark.parametrize("kw", [dict(ordering=0, streams=1), dict(ordering=0, streams=2), dict(ordering=2, streams=1), dict(ordering=2, streams=2),
+                                dict(ordering=2, streams=1, batch=3)])
+@pytest.mark.parametrize("extra", [251, 594, 1494])
+def test_more_than_256_primitives_match_the_oracle(pt, extra, kw):
+    depth, iters = 6, 2
+    sc, want, live, (on, oarrs, opix) = _oracle(extra, depth, iters)
+    assert sc.G == extra + 6 and sc.G > 256
+    tr = make_tracer(sc, depth=depth, **kw)
+    tr.set_image(None)
+    tr.render(1, iters)
+    st = tr.stats()
+    assert [st.live[k] for k in range(depth + 1)] == [int(v) for v in live], (sc.G, kw)
+    assert np.array_equal(tr.image(), want), (sc.G, kw)
+    if kw.get("streams", 1) == 1:
+        n, arrs, pix = tr.trace_pool(2, 3)
+        order = np.argsort(pix, kind="stable")
+        pix, arrs = pix[order], [x[order] for x in arrs]
+        assert n == on and np.array_equal(pix, opix) and all(np.array_equal(a, b) for a, b in zip(arrs, oarrs)), (sc.G, kw)
+    tr.close()
+
+
+def test_more_than_256_primitives_with_direct_light_and_flat_mode(pt):
+    """the other launch paths a big scene can take: direct light (per-bounce kernels) and mode 1 (the reference kernel as shipped)"""
+    sc = orc.many_primitives_scene(594)
+    tr = make_tracer(sc, depth=5, direct_light=1)
+    tr.set_image(None); tr.render(1, 2)
+    want, live = orc.render(sc, oracle_config(5, direct_light=1), 1, 2)
+    st = tr.stats()
+    assert [st.live[k] for k in range(6)] == [int(v) for v in live]
+    assert np.array_equal(tr.image(), want)
+    tr.close()
+    flat, hit = orc.raycast_flat(sc)
+    trf = make_tracer(sc, mode=1)
+    trf.set_image(None); trf.render(1, 1)
+    assert np.array_equal(trf.image(), flat)
+    trf.close()
