@@ -346,11 +346,13 @@ class PathTracer:
 
 def grid_probe(geoms, rays, density=0):
     """k_path_w's spatial index probed on the host (no device): (sets, info) for rays[n, 6] = origin + direction.
-    sets[n, 256] (bool): primitive p gets its bound tested for ray n; info: dict of the grid's figures."""
+    sets[n, max(256, G rounded up to 32)] (bool): primitive p gets its bound tested for ray n; info: dict of the grid's figures.
+    Up to 256 primitives the grid has narrow (16-bit) references, beyond that wide ones -- as pt_upload_scene builds it."""
     import numpy as np
     rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
     n = rays.shape[0]
-    words = np.zeros((n, 8), dtype=np.uint32)
+    nwords = max(8, (len(geoms) + 31) // 32)
+    words = np.zeros((n, nwords), dtype=np.uint32)
     info = np.zeros(24, dtype=np.uint32)
     _check(lib().pt_debug_grid_probe(geoms, len(geoms), int(density), _fp(rays), n,
                                      words.ctypes.data_as(C.POINTER(C.c_uint32)), info.ctypes.data_as(C.POINTER(C.c_uint32))))

@@ -693,7 +693,12 @@ constexpr uint32_t kWPayload = 16;   // k_path_w: floats per payload record in g
 // primitive's (box-shaped) cell range are consecutive, so the primitive is new in a cell exactly when the step into
 // that cell crossed the range's boundary on one of the axes stepped -- or when the cell is the ray's first.
 constexpr int kGridBigCells = 27;
-constexpr uint32_t kGridMaxCells = 8192;            // 13 bits of a pair entry
+constexpr uint32_t kGridMaxCells = 8192;            // narrow references: 13 bits of a pair entry hold a reference index
+// More than 256 primitives (k_path_w<BIG>): the same grid with WIDE references -- cells[ncells] hold the index of the cell's first
+// reference (0xFFFFFFFF: empty), a reference is primitive id | flags << 24 (same flag bits), big[nbig] are 32-bit ids; the blob is
+// staged in LDS when it fits beside the waves' regions and read from global memory otherwise.
+constexpr uint32_t kGridMaxCellsWide = 1u << 18;    // (cell addresses are rebuilt in float: exact far beyond this)
+constexpr uint32_t kGridMaxRefsWide = (1u << 18) - 1u;   // 18 bits of a pair entry hold a reference index
 struct GridArgs {
     float gmin[3];                   // lower corner
     float h[3], inv_h[3];            // cell size per axis and its reciprocal
@@ -776,7 +781,8 @@ __host__ __device__ __forceinline__ void grid_walk_step(GridWalk &w) {
 }
 
 // a reference (GridArgs) is new to a ray in a cell entered with `emask`
-__host__ __device__ __forceinline__ bool grid_ref_is_new(uint32_t ref, uint32_t emask) { return ((((ref >> 8) & 0x3Fu) | 0x40u) & emask) != 0u; }
+__host__ __device__ __forceinline__ bool grid_flags_new(uint32_t flags, uint32_t emask) { return (((flags & 0x3Fu) | 0x40u) & emask) != 0u; }
+__host__ __device__ __forceinline__ bool grid_ref_is_new(uint32_t ref, uint32_t emask) { return grid_flags_new(ref >> 8, emask); }    // narrow reference
 
 // cells the walk of a ray will visit, estimated: 1 + the cell boundaries its span inside the grid's box crosses, counted as
 // the span's extent in cell units per axis (off by at most one and a half cells; 0: the ray misses the box).  k_path_w sorts the

@@ -183,3 +183,26 @@ def test_grid_when_everything_is_big_or_flat(pt):
             finite = np.isfinite(rays).all(1)
             need = _meets(rays[finite].astype(np.float64), lo, hi)
             assert not (need & ~sets[finite][:, ids]).any(), (name, fam, info)
+
+
+@pytest.mark.parametrize("extra,density", [(251, 0), (594, 0), (1494, 0), (1494, 2), (5000, 0)])
+def test_wide_grid_lists_every_primitive_a_ray_meets_exactly_once(pt, extra, density):
+    """More than 256 primitives: the same grid with 32-bit references and ids (k_path_w<BIG>), as pt_upload_scene builds it.
+    Complete, listed once, bounded -- on the scenes tests/test_gpu_many_primitives.py renders and on a 5 006-primitive one."""
+    sc = orc.many_primitives_scene(extra, size=(0.12, 0.5) if extra < 3000 else (0.05, 0.25))
+    geoms, _, _ = to_product(sc)
+    lo, hi, ids = _boxes(sc.geoms)
+    rng = np.random.default_rng(extra + density)
+    total = 0
+    for name, rays in _ray_families(lo, hi, rng, 1500).items():
+        sets, info = pt.grid_probe(geoms, rays, density)
+        assert info["duplicates"] == 0, (name, info)
+        assert info["longest_walk"] <= info["nx"] + info["ny"] + info["nz"], (name, info)
+        assert info["big"] <= 16 and info["refs"] < (1 << 18)
+        finite = np.isfinite(rays).all(1)
+        need = _meets(rays[finite].astype(np.float64), lo, hi)
+        have = sets[finite][:, ids]
+        missing = need & ~have
+        assert not missing.any(), (name, extra, density, np.argwhere(missing)[:5], info)
+        total += int(need.sum())
+    assert total > 5000
