@@ -39,6 +39,8 @@ WORKLOADS = {
     "c3": ("scenes/cornell_mirror.txt", 8, "configs[2]: Cornell box 1920x1080, 8 bounces, diffuse + perfect specular, compaction on"),
     "c2": ("scenes/cornell.txt", 8, "configs[1]: sampleScene-equivalent Cornell box 800x800, 8 bounces, diffuse only"),
     "c4": ("scenes/random256.txt", 8, "configs[3]: 1920x1080, 8 bounces, 256 random spheres+cubes"),
+    # beyond 256 primitives (the reference's loop takes any numberOfGeoms): not a BASELINE config
+    "c1k": ("scenes/random1024.txt", 8, "1920x1080, 8 bounces, 1 024 random spheres+cubes (more than 256 primitives: k_path_w with wide ids)"),
     "c5": ("scenes/cornell_glass_4k.txt", 16, "configs[4]: 3840x2160, 16 bounces, Fresnel refraction + depth of field + jittered AA"),
     # GEOMTYPE MESH (the reference declares the type and leaves its kernel branch empty): not a BASELINE config
     "mesh": ("scenes/cornell_mesh.txt", 8, "MESH: Cornell box 1920x1080, 8 bounces, icosphere (80 triangles) + torus (400) + glass tetrahedron beside a sphere and a cube"),
@@ -433,8 +435,9 @@ def main():
             kernel = "k_path_q (whole paths, one launch per group: generate + cull + exact tests + scatter + accumulate; rays between bounces on per-wave stacks)"
         elif args.ordering == 2 and args.direct_light and nprims <= 32 and not meshes:
             kernel = "k_path_q<NEE> (whole paths, one launch per group; the shadow ray of a diffuse hit is a record of the same typed queues, resolved before the scattered ray goes on)"
-        elif args.ordering == 2 and not args.direct_light and nprims <= 256 and not meshes:
-            kernel = "k_path_w (whole paths, one launch per group, 33..256 primitives: grid walk, dense (ray, cell reference) and (ray, primitive) pairs, type-pure exact tests, shading stage by hit type; rays between bounces on per-wave stacks sorted by walk length)"
+        elif args.ordering == 2 and not args.direct_light and not meshes:
+            kernel = "k_path_w (whole paths, one launch per group, more than 32 primitives: grid walk, dense (ray, cell reference) and (ray, primitive) pairs, type-pure exact tests, shading stage by hit type; rays between bounces on per-wave stacks sorted by walk length" + \
+                     ("; byte ids, geometry table in LDS)" if nprims <= 256 else "; wide ids, geometry gathered from global memory)")
         elif args.ordering in (1, 2) and not args.direct_light and nprims <= 32:
             kernel = "k_bounce_q (typed work queues, one launch per bounce)"
         else:

@@ -49,7 +49,8 @@ struct pt_context {
     int grid_path = 0;
     uint32_t path_static_eighths = 4;
     uint32_t path_waves = 4;         //   waves per block of the whole-path kernel in use
-    int wide_variant = 0;            //   k_path_w: block shape / slots per wave (cfg.wide_variant)
+    int wide_shape = 0;              //   k_path_w: block shape (0 / 1 narrow ids, 2 / 3 wide ids: pt_k_wide.hip)
+    bool wide_big = false;           //   more than 256 primitives: wide ids, geometry gathered from global memory
     uint32_t wide_stack = 0, wide_slots = 0;
     float wide_qscale = 1.0f, wide_slack = 0.0f;
     GridArgs grid;                   //   k_path_w: the uniform grid over the small primitives (build_grid)
@@ -282,7 +283,7 @@ int enqueue_iterations(pt_context *c, uint32_t iteration, uint32_t batch, int st
         HIPCHK(hipMemsetAsync(pa.ticket, 0, (size_t)kTicketCtrs * kTicketStride * sizeof(uint32_t), c->stream));
         {
             Scoped s(c, 1);
-            if (c->pathw) wide_launch(c->wide_variant, c->grid_path, c->lds_path, c->stream, a, pa, c->grid, c->d_geoms, c->d_mats, c->d_frames);
+            if (c->pathw) wide_launch(c->wide_shape, c->grid_path, c->lds_path, c->stream, a, pa, c->grid, c->d_geoms, c->d_mats, c->d_frames);
             else path_launch(c->queue_mesh, c->pathq_nee, c->path_cap, c->grid_path, c->lds_path, c->stream, a, pa, c->d_geoms, c->d_mats, qt);
             HIPCHK(hipGetLastError());
         }
@@ -564,11 +565,36 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
     // 33..256 analytic primitives with the table in LDS: two-level cluster culling (the stable kernel's WIDE variant;
     // with ordering = 2 the whole-path kernel k_path_w renders and this variant serves the parity hooks)
     c->wide = c->cull && c->geom_lds && !c->nee && !c->queue && !have_mesh && c->cfg.mode == 0 && G > 32 && G <= 256;
-    c->pathw = c->wide && c->cfg.ordering == 2;                 // (kept when the clusters below do not fit their mask: k_path_w has its own index)
-    // k_path_w's smallest block shape needs 91 136 bytes beside the tables and at least a small grid (1 KB): with several hundred
-    // materials the tables alone leave less -- such a scene stays on the per-bounce kernels (decided HERE: the launch-group size and
-    // the pools below depend on it)
-    if (c->pathw && (int64_t)160 * 1024 - (int64_t)tables_bytes(G, M, true) - 91136 < 1024) c->pathw = false;
+    // ordering = 2 with more than 32 analytic primitives: whole paths on k_path_w, ANY count (the reference's loop takes any
+    // numberOfGeoms, src/raytraceKernel.cu:137-153,192-194) -- up to 256 with byte ids and the geometry table in LDS, beyond that with
+    // wide ids and the geometry gathered from global memory.  Planned HERE (grid, block shape, LDS): the launch-group size and the
+    // pools below depend on whether it renders; a scene whose tables leave no room for any shape stays on the per-bounce kernels.
+    c->pathw = c->cull && !c->nee && !c->queue && !have_mesh && c->cfg.mode == 0 && c->cfg.ordering == 2 && G > 32 && G < (1 << 21);
+    pth::GridBuild gb;
+    WideLayout wl;
+    memset(&wl, 0, sizeof wl);
+    if (c->pathw) {
+        c->wide_big = G > 256;
+        if (!c->wide_big) {
+            // (the smallest narrow shape needs 91 136 bytes beside the tables; at least 1 KB of grid)
+            const int64_t grid_room = (int64_t)160 * 1024 - (int64_t)tables_bytes(G, M, true) - 91136;
+            if (grid_room < 1024) c->pathw = false;
+            else {
+                pth::build_grid(g, G, c->cfg.grid_density, (size_t)(grid_room < 24 * 1024 ? grid_room : 24 * 1024), false, &gb);
+                c->wide_shape = 0;
+                if (wide_lds_bytes(0, G, M, gb.ga.blob_bytes) > 160u * 1024u) c->wide_shape = 1;
+                if (wide_lds_bytes(c->wide_shape, G, M, gb.ga.blob_bytes) > 160u * 1024u) c->pathw = false;
+            }
+        } else {
+            pth::build_grid(g, G, c->cfg.grid_density, 0, true, &gb);
+            // the grid in LDS beside the larger shape, else beside the smaller one, else in global memory with the larger shape
+            gb.ga.in_lds = 1u;
+            c->wide_shape = 2;
+            if (wide_lds_bytes(2, G, M, gb.ga.blob_bytes) > 160u * 1024u) c->wide_shape = 3;
+            if (wide_lds_bytes(c->wide_shape, G, M, gb.ga.blob_bytes) > 160u * 1024u) { gb.ga.in_lds = 0u; c->wide_shape = 2; }
+            if (wide_lds_bytes(c->wide_shape, G, M, gb.ga.in_lds ? gb.ga.blob_bytes : 0u) > 160u * 1024u) c->pathw = false;     // (thousands of materials)
+        }
+    }
     // two-level culling of the many-primitive variant: clusters of <= kClusterMax primitives of one type (pt_build.cpp)
     std::vector<unsigned char> cluster_blob;
     c->nbc = c->nsc = 0; c->cluster_bytes = 0;
@@ -720,24 +746,13 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         HIPCHK(hipMalloc(&c->d_tickets, (size_t)kTicketCtrs * kTicketStride * sizeof(uint32_t)));
     }
     if (c->pathw) {
-        // ordering = 2 with 33..256 analytic primitives: k_path_w -- one big block per CU shares the geometry table; per-wave
-        // ray slots and work stacks in LDS, the survivors' stacks and the slots' payload in one arena per wave
-        pth::GridBuild gb;
-        // (the smallest block shape of k_path_w leaves 160 KB - tables - 89 KB to the grid)
-        const size_t grid_room = (size_t)((int64_t)160 * 1024 - (int64_t)tables_bytes(G, M, true) - 91136);      // >= 1 KB: checked where pathw was decided
-        pth::build_grid(g, G, c->cfg.grid_density, grid_room < 24u * 1024u ? grid_room : 24u * 1024u, false, &gb);
+        // k_path_w -- one big block per CU; per-wave ray slots and work stacks in LDS, the survivors' stacks and the slots' payload
+        // in one arena per wave (grid and block shape: planned above)
         c->grid = gb.ga;
         HIPCHK(hipMalloc(&c->d_grid, gb.blob.size()));
         HIPCHK(hipMemcpy(c->d_grid, gb.blob.data(), gb.blob.size(), hipMemcpyHostToDevice));
         c->grid.blob = c->d_grid;
-        WideLayout wl;
-        c->wide_variant = c->cfg.wide_variant;
-        {
-            // the block shape asked for, or the next one that leaves room for the grid beside the tables
-            hipError_t e = wide_setup(c->wide_variant, G, M, c->grid.blob_bytes, &wl);
-            for (int v = 3; e == hipErrorInvalidValue && v >= 1; --v) { c->wide_variant = v; e = wide_setup(v, G, M, c->grid.blob_bytes, &wl); }
-            HIPCHK(e);
-        }
+        HIPCHK(wide_setup(c->wide_shape, G, M, (!c->wide_big || c->grid.in_lds) ? c->grid.blob_bytes : 0u, &wl));
         c->lds_path = wl.lds_bytes;
         c->path_waves = wl.waves_per_block;
         c->grid_path = c->n_cu;
@@ -753,7 +768,7 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
                 smax = std::fmax(smax, (double)g[i].slack);
             }
             const double diag = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
-            c->wide_qscale = (float)(250.0 / (diag > 0.0 ? diag : 1.0));
+            c->wide_qscale = (float)((c->wide_big ? 1000.0 : 250.0) / (diag > 0.0 ? diag : 1.0));
             c->wide_slack = (float)smax;
         }
         c->arena_bytes = (size_t)c->grid_path * wl.waves_per_block * ((size_t)kWalkBins * kSFields * wl.stack_slots + (size_t)kWPayload * wl.payload_per_wave) * sizeof(float);
@@ -937,6 +952,10 @@ extern "C" int pt_debug_wide_stats(unsigned long long *out32) { stats_wide(out32
 // does and walks `nrays` rays (o.xyz, d.xyz each) ON THE HOST with the kernel's own walk functions and flag logic.
 int pt_debug_grid_probe(const pt_geom *geoms, int G, int density, const float *rays, int nrays, uint32_t *out_sets, uint32_t *out_info) {
     return pth::grid_probe(geoms, G, density, rays, nrays, out_sets, out_info);
+}
+
+int pt_debug_fan_probe(const pt_geom *geoms, int G, const float *rays, int nfans, uint32_t *out_sets, uint32_t *out_info) {
+    return pth::fan_probe(geoms, G, rays, nfans, out_sets, out_info);
 }
 
 int pt_set_profiling(pt_context *c, int enabled) {

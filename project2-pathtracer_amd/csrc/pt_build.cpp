@@ -512,4 +512,38 @@ int grid_probe(const pt_geom *geoms, int G, int density, const float *rays, int 
     return PT_OK;
 }
 
+// ---- pt_debug_fan_probe: the cone test of k_path_w's camera groups on the host --------------------------------------
+// rays: nfans x 64 x (origin, direction); out_sets: max(8, ceil(G / 32)) words per fan, bit p = the cone of the fan meets primitive
+// p's bound (all ones when the fan gets no cone: the kernel then walks the grid); out_info[0] = fans that got a cone.
+int fan_probe(const pt_geom *geoms, int G, const float *rays, int nfans, uint32_t *out_sets, uint32_t *out_info) {
+    if (!geoms || G < 1 || !rays || nfans < 0 || !out_sets || !out_info) { set_error("pt_debug_fan_probe: bad argument"); return PT_ERR_ARGUMENT; }
+    std::vector<GeomRec> g(G);
+    for (int i = 0; i < G; ++i) { memset(&g[i], 0, sizeof(GeomRec)); g[i].type = geoms[i].type; world_bounds(geoms[i], &g[i]); }
+    const size_t words = (size_t)std::max(8, (G + 31) / 32);
+    uint32_t cones = 0;
+    for (int f = 0; f < nfans; ++f) {
+        const float *r = rays + (size_t)f * 64 * 6;
+        uint32_t *set = out_sets + (size_t)f * words;
+        const f3 e = mk(r[0], r[1], r[2]);
+        const f3 ax = fan_axis(mk(r[3], r[4], r[5]), mk(r[63 * 6 + 3], r[63 * 6 + 4], r[63 * 6 + 5]));
+        float md = 1.0f;
+        bool same = true;
+        for (int l = 0; l < 64; ++l) {
+            const float *q = r + 6 * l;
+            float dt = __builtin_fmaf(q[5], ax.z, __builtin_fmaf(q[4], ax.y, q[3] * ax.x));
+            if (!(dt == dt)) dt = -1.0f;
+            md = std::fmin(md, dt);
+            same = same && q[0] == e.x && q[1] == e.y && q[2] == e.z;
+        }
+        FanCone cone;
+        if (!(fan_finish(e, ax, md, cone) && same)) { for (size_t k = 0; k < words; ++k) set[k] = 0xFFFFFFFFu; continue; }
+        cones++;
+        for (size_t k = 0; k < words; ++k) set[k] = 0u;
+        for (int p = 0; p < G; ++p)
+            if ((g[p].type == 0 || g[p].type == 1) && fan_meets(g[p].bmin, g[p].bmax, g[p].type == 0, cone)) set[p >> 5] |= 1u << (p & 31);
+    }
+    out_info[0] = cones;
+    return PT_OK;
+}
+
 }  // namespace pth

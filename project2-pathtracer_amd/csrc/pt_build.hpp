@@ -35,5 +35,7 @@ void mesh_world_bounds(const pt_geom &src, const HostMesh &hm, ptd::GeomRec *dst
 
 // the walk of k_path_w on the host (pt_debug_grid_probe): see include/ptmi355.h
 int grid_probe(const pt_geom *geoms, int G, int density, const float *rays, int nrays, uint32_t *out_sets, uint32_t *out_info);
+// the cone test of k_path_w's camera groups on the host (pt_debug_fan_probe)
+int fan_probe(const pt_geom *geoms, int G, const float *rays, int nfans, uint32_t *out_sets, uint32_t *out_info);
 
 }  // namespace pth

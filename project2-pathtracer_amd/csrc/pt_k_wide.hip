@@ -61,39 +61,59 @@ __device__ __forceinline__ void wstat(int i, unsigned long long v) { if ((thread
 #define PT_WSTAT(i, v) do { } while (0)
 #endif
 
+#ifndef PT_FAN
+#define PT_FAN 1                        // camera groups take one cone test per primitive instead of 64 grid walks (A/B switch; results identical)
+#endif
+
 namespace {
 
-// slot fields (SoA, stride R dwords, wave-private LDS)
-enum : uint32_t { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_L0, F_L1, F_L2, F_L3, F_META, F_BEST, F_COUNT };
+// slot fields (SoA, stride R dwords, wave-private LDS): origin, direction | the candidate list | meta word | best depth [| best hit]
+// narrow (<= 256 primitives): 8 keys of 16 bits in 4 words; wide (BIG): 8 keys of 32 bits, and the best hit's id in a word of its own
+enum : uint32_t { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_L0 };
+template <bool BIG> struct WFmt;
+template <> struct WFmt<false> {
+    static constexpr uint32_t kListWords = 4, kMeta = F_L0 + 4, kBest = kMeta + 1, kHit = kBest, kFields = 12;   // (kHit unused)
+    static constexpr uint32_t kQMax = 254u, kEmpty = 0xFFFFu;           // quantised entry distance 0..254 (255 would collide with the empty key)
+    static constexpr uint32_t kSidBits = 8, kRefShift = 8, kRefMask = 0x1FFFu, kEmaskShift = 21;        // (ray, cell reference) entry: sid | ref index | entry flags
+};
+template <> struct WFmt<true> {
+    static constexpr uint32_t kListWords = 8, kMeta = F_L0 + 8, kBest = kMeta + 1, kHit = kBest + 1, kFields = 17;
+    static constexpr uint32_t kQMax = 1022u, kEmpty = 0xFFFFFFFFu;      // key = q << 22 | sphere << 21 | id (21 bits)
+    static constexpr uint32_t kSidBits = 7, kRefShift = 7, kRefMask = 0x3FFFFu, kEmaskShift = 25;
+};
+constexpr uint32_t kBigIdMask = 0x1FFFFFu, kBigSphere = 1u << 21;
 // payload fields (SoA, stride R floats, global memory, per wave)
 // payload record (global memory, per wave): ONE 64-byte line per ray, four 16-byte quarters -- a lane of a TEST or SHADE group
 // holds some ray of the wave, so field-major arrays would cost it a different cache line per field:
-//   Q_THR throughput.xyz, pixel word | Q_DIR level, direction.xyz | Q_HIT best hit's point.xyz, hit | (face + 1) << 8 | Q_NRM its normal.xyz (spheres), -
+//   Q_THR throughput.xyz, pixel word | Q_DIR level, direction.xyz | Q_HIT best hit's point.xyz, hit | (face + 1) << 8 (wide ids: << 24) | Q_NRM its normal.xyz (spheres), -
 enum : uint32_t { Q_THR = 0, Q_DIR = 1, Q_HIT = 2, Q_NRM = 3 };
 static_assert(kWPayload == 16, "payload record: one 64-byte line");
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 static_assert(kWalkBins == 3, "the survivors' stacks are written out as sp0, sp1, sp2");
 static_assert(100 * 4 + sizeof(GridArgs) <= kCtrlBytes, "the parked GridArgs must fit behind the survivors' counters in the control block");
 
-constexpr uint32_t kMetaHasHit = 1u << 27;      // slot word while a ray waits for a TEST: candidate | best hit << 8 | (face + 1) << 16 | payload id << 19 | this bit
+constexpr uint32_t kMetaHasHit = 1u << 27;      // narrow slot word while a ray waits for a TEST: candidate | best hit << 8 | (face + 1) << 16 | payload id << 19 | this bit
+                                                // wide: candidate (21 bits) | (face + 1) << 21 | payload id << 24; hit word: best hit | hit is a cube << 30 | has a hit << 31
 constexpr uint32_t kListCap = 8;
 constexpr uint32_t kBufA = 128;        // (ray, cell) entries: a walk trip adds <= 64 to <= 63 waiting
 constexpr uint32_t kBufC = 192;        // (ray, primitive) entries, cubes from the bottom, spheres from the top: a CELLS trip adds <= 64 to <= 63 + 63
 
-// quantised conservative entry distance: floor(max(tn, 0) * qscale), 0..254 (255 would collide with the empty key 0xFFFF)
+// quantised conservative entry distance: floor(max(tn, 0) * qscale), 0..kQMax
+template <bool BIG>
 __device__ __forceinline__ uint32_t quant_tn(float tn, float qscale) {
-    const float v = fminf(fmaxf(tn, 0.0f) * qscale, 254.0f);
+    const float v = fminf(fmaxf(tn, 0.0f) * qscale, (float)WFmt<BIG>::kQMax);
     return (uint32_t)v;
 }
 
-// the smallest viable key among the 8 entries of a list: key = q << 8 | id, empty = 0xFFFF; viable: q <= qmax.
-// Returns the key (0xFFFF: none) and its position.
-__device__ __forceinline__ uint32_t select_next(const uint32_t L[4], uint32_t qmax, uint32_t &pos) {
-    uint32_t bestk = 0xFFFFu, bestp = 0u;
-    const uint32_t limit = (qmax << 8) | 0xFFu;           // keys above it are beyond the best hit (and 0xFFFF > limit: qmax <= 254)
+// the smallest viable key among the 8 entries of a list (narrow: key = q << 8 | id, 16 bits, two per word; wide: q << 22 | sphere << 21 | id);
+// viable: q <= qmax.  Returns the key (kEmpty: none) and its position.
+template <bool BIG>
+__device__ __forceinline__ uint32_t select_next(const uint32_t *L, uint32_t qmax, uint32_t &pos) {
+    uint32_t bestk = WFmt<BIG>::kEmpty, bestp = 0u;
+    const uint32_t limit = BIG ? ((qmax << 22) | 0x3FFFFFu) : ((qmax << 8) | 0xFFu);           // keys above it are beyond the best hit (and kEmpty > limit: qmax <= kQMax)
 #pragma unroll
     for (uint32_t k = 0; k < kListCap; ++k) {
-        const uint32_t key = (k & 1u) ? (L[k >> 1] >> 16) : (L[k >> 1] & 0xFFFFu);
+        const uint32_t key = BIG ? L[k] : ((k & 1u) ? (L[k >> 1] >> 16) : (L[k >> 1] & 0xFFFFu));
         const bool better = key <= limit && key < bestk;
         bestk = better ? key : bestk;
         bestp = better ? k : bestp;
@@ -104,10 +124,13 @@ __device__ __forceinline__ uint32_t select_next(const uint32_t L[4], uint32_t qm
 
 }  // namespace
 
-template <int WAVES, int R, int NP>
+template <int WAVES, int R, int NP, bool BIG>
 __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, GridArgs ga, const GeomRec *__restrict__ geoms,
                                                         const MatRec *__restrict__ mats, const FaceFrame *__restrict__ frames) {
     static_assert(R % 4 == 0 && NP % 4 == 0 && R <= 256 && NP <= 256 && NP >= R + 64, "slot and payload ids are bytes");
+    static_assert(!BIG || R <= 128, "wide pair entries keep the slot id in 7 bits");
+    typedef WFmt<BIG> Fm;
+    constexpr uint32_t F_META = Fm::kMeta, F_BEST = Fm::kBest, F_HIT = Fm::kHit, NF = Fm::kFields, LW = Fm::kListWords;
     // survivors wait for their next bounce on kWalkBins stacks, sorted by the length of the walk ahead of them, so that the rays of
     // a FRESH group walk about equally far.  New (camera) rays only enter while no stack holds a full wave and 64 payload records
     // are free, so the wave never holds more than NP + 63 * kWalkBins rays in all: no stack outgrows STK
@@ -125,32 +148,45 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
         park[8] = a.cam.mS; park[9] = a.cam.shS;
         *reinterpret_cast<GridArgs *>(ctrl + 100) = ga;    // the walk's set-up reads the grid's figures from here: the scalar file is full,
     }                                                      // and a spilled scalar costs a lane read per use
-    // the grid blob goes behind the geometry table (stage_tables ends with the block's barrier)
-    const uint32_t tb = tables_bytes(a.G, a.M, true);
-    {
+    // the grid blob goes behind the tables (stage_tables ends with the block's barrier).  Narrow: always; wide: when the host found
+    // room for it (ga.in_lds) -- else cells, references and the big list are read from the device copy
+    const uint32_t tb = tables_bytes(a.G, a.M, !BIG);
+    const bool grid_lds = !BIG || ga.in_lds != 0u;
+    const uint32_t grid_lds_bytes = grid_lds ? ga.blob_bytes : 0u;
+    if (grid_lds) {
         uint32_t *gdst = reinterpret_cast<uint32_t *>(smem + tb);
         const uint32_t *gsrc = reinterpret_cast<const uint32_t *>(ga.blob);
         for (uint32_t i = threadIdx.x; i < ga.blob_bytes / 4u; i += blockDim.x) gdst[i] = gsrc[i];
     }
-    GeomRec *lg;
+    GeomRec *lg_lds;
     MatRec *lm;
-    stage_tables(smem, geoms, a.G, mats, a.M, true, lg, lm);
+    stage_tables(smem, geoms, a.G, mats, a.M, !BIG, lg_lds, lm);
+    // the geometry table: LDS (narrow) or the device array itself (wide: per-lane gathers through the vector cache)
+    const GeomRec *lg;
+    if constexpr (BIG) lg = geoms; else lg = lg_lds;
     const uint32_t *cells = reinterpret_cast<const uint32_t *>(smem + tb);
-    const unsigned short *refs = reinterpret_cast<const unsigned short *>(cells + ga.ncells);
+    const unsigned short *refs = reinterpret_cast<const unsigned short *>(cells + ga.ncells);                 // narrow
     const unsigned char *bigs = reinterpret_cast<const unsigned char *>(refs + ((ga.nrefs + 1u) & ~1u));
+    const uint32_t *gcells = reinterpret_cast<const uint32_t *>(ga.blob);                                    // wide, grid in global memory
+    const uint32_t *refs32 = cells + ga.ncells, *grefs32 = gcells + ga.ncells;                                // wide
     const int nbig = (int)ga.nbig;
+    auto ld_cell = [&](uint32_t i) -> uint32_t { if constexpr (BIG) { return grid_lds ? cells[i] : gcells[i]; } else { return cells[i]; } };
+    auto ld_ref32 = [&](uint32_t i) -> uint32_t { return grid_lds ? refs32[i] : grefs32[i]; };
+    auto ld_big = [&](int k) -> uint32_t {                                     // wave-uniform index
+        if constexpr (BIG) { return grid_lds ? refs32[ga.nrefs + (uint32_t)k] : grefs32[ga.nrefs + (uint32_t)k]; } else { return (uint32_t)bigs[k]; }
+    };
 
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     const uint32_t wslot = blockIdx.x * WAVES + wave;
     const uint32_t nwaves = gridDim.x * WAVES;
     const uint32_t D = pa.depth;
-    // the wave's LDS region: 12 slot fields x R | byte lists: typed stacks of slot ids waiting for a TEST (cubes up, spheres down),
+    // the wave's LDS region: NF slot fields x R | byte lists: typed stacks of slot ids waiting for a TEST (cubes up, spheres down),
     // free slots, free payload records, typed stacks of payload ids waiting for SHADE (cube hits up, sphere hits down) | the two pair buffers
     constexpr uint32_t kListDwords = (2u * R + 2u * NP) / 4u;
-    uint32_t *wl = reinterpret_cast<uint32_t *>(smem + tb + ga.blob_bytes) + (size_t)wave * (12u * R + kListDwords + kBufA + kBufC);
+    uint32_t *wl = reinterpret_cast<uint32_t *>(smem + tb + grid_lds_bytes) + (size_t)wave * (NF * R + kListDwords + kBufA + kBufC);
     float *wf = reinterpret_cast<float *>(wl);
-    unsigned char *xstack = reinterpret_cast<unsigned char *>(wl + 12u * R), *freel = xstack + R, *pfree = freel + R, *shstack = pfree + NP;
-    uint32_t *bufA = wl + 12u * R + kListDwords, *bufC = bufA + kBufA;
+    unsigned char *xstack = reinterpret_cast<unsigned char *>(wl + NF * R), *freel = xstack + R, *pfree = freel + R, *shstack = pfree + NP;
+    uint32_t *bufA = wl + NF * R + kListDwords, *bufC = bufA + kBufA;
     for (uint32_t i = lane; i < (uint32_t)R; i += 64u) freel[i] = (unsigned char)i;
     for (uint32_t i = lane; i < (uint32_t)NP; i += 64u) pfree[i] = (unsigned char)i;
     uint32_t nfree = R, npfree = NP;
@@ -168,6 +204,22 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
         __builtin_amdgcn_raw_buffer_store_b128(v, rs, (poff + pid * kWPayload) * 4u, q * 16u, 0);
     };
 
+    // entry `pos` (< kListCap) of slot `sid`'s candidate list: quantised entry distance, primitive, its type
+    auto list_put = [&](uint32_t sid_, uint32_t pos, uint32_t q, uint32_t prim, bool sphere) {
+        if constexpr (BIG) wl[(F_L0 + pos) * R + sid_] = (q << 22) | (sphere ? kBigSphere : 0u) | prim;
+        else {
+            unsigned short *l16 = reinterpret_cast<unsigned short *>(&wl[(F_L0 + (pos >> 1)) * R + sid_]) + (pos & 1u);
+            *l16 = (unsigned short)((q << 8) | prim);
+        }
+    };
+    // entry `pos` leaves the list (L = the list's words as read)
+    auto list_clear = [&](uint32_t sid_, uint32_t pos, const uint32_t *L) {
+        if constexpr (BIG) wl[(F_L0 + pos) * R + sid_] = 0xFFFFFFFFu;
+        else {
+            const uint32_t clr = (pos & 1u) ? 0xFFFF0000u : 0x0000FFFFu;
+            wl[(F_L0 + (pos >> 1)) * R + sid_] = L[pos >> 1] | clr;
+        }
+    };
     uint32_t *bank = a.bank ? a.sync->counts_b : a.sync->counts;
     if (blockIdx.x == 0 && threadIdx.x < 72) {
         uint32_t *other = a.bank ? a.sync->counts : a.sync->counts_b;
@@ -314,30 +366,63 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
                 pid = pfree[npfree - 1u - wave_rank(vb)];
                 wf[F_OX * R + sid] = o.x; wf[F_OY * R + sid] = o.y; wf[F_OZ * R + sid] = o.z;
                 wf[F_DX * R + sid] = d.x; wf[F_DY * R + sid] = d.y; wf[F_DZ * R + sid] = d.z;
-                wl[F_L0 * R + sid] = 0xFFFFFFFFu; wl[F_L1 * R + sid] = 0xFFFFFFFFu; wl[F_L2 * R + sid] = 0xFFFFFFFFu; wl[F_L3 * R + sid] = 0xFFFFFFFFu;
+#pragma unroll
+                for (uint32_t k = 0; k < LW; ++k) wl[(F_L0 + k) * R + sid] = 0xFFFFFFFFu;
                 // what only the shading needs waits in the ray's payload record: throughput, pixel word, level, direction
                 pay_st(pid, Q_THR, thr.x, thr.y, thr.z, __uint_as_float(pv));
                 pay_st(pid, Q_DIR, __uint_as_float(level), d.x, d.y, d.z);
             }
             nfree -= nv; npfree -= nv;
             const CullRay cr = make_cull_ray(o, d);
-            // ---------------------------------------------------------------- the big primitives: every ray, wave-uniform index
             uint32_t ncand0 = 0u;
-            for (int k = 0; k < nbig; ++k) {
-                const uint32_t p = (uint32_t)__builtin_amdgcn_readfirstlane((int)bigs[k]);
+            // one wave-uniform primitive against the group's rays: its own bound per lane, a passing one joins the lane's list
+            auto bound_vs_group = [&](uint32_t p) {
                 const GeomRec *g = lg + p;
                 float tn;
                 bool keep;
-                if (__builtin_amdgcn_readfirstlane(g->type) == 1) keep = cull_box(g->bmin, g->bmax, cr, tn);
+                const bool pbox = __builtin_amdgcn_readfirstlane(g->type) == 1;
+                if (pbox) keep = cull_box(g->bmin, g->bmax, cr, tn);
                 else keep = cull_sphere(g->bmin, g->bmax, cr, tn);
                 if (keep && valid) {
-                    if (ncand0 < kListCap) {
-                        unsigned short *l16 = reinterpret_cast<unsigned short *>(&wl[(F_L0 + (ncand0 >> 1)) * R + sid]) + (ncand0 & 1u);
-                        *l16 = (unsigned short)((quant_tn(tn, qscale) << 8) | p);
-                    }
+                    if (ncand0 < kListCap) list_put(sid, ncand0, quant_tn<BIG>(tn, qscale), p, !pbox);
                     ncand0++;
                 }
+            };
+            // ---------------------------------------------------------------- camera rays: ONE cone for the group instead of 64 walks
+            // (pt_kernels.hpp, fan_*): lane = one primitive, its bound against the cone; the few it meets are tested by the rays.
+            bool fan = false;
+            if (PT_FAN && act == 3 && a.G <= kFanMaxPrims) {
+                const int l0 = (int)__builtin_ctzll(vb), l1 = 63 - (int)__builtin_clzll(vb);            // (a FRESH group has a valid lane)
+                const f3 e = mk(__shfl(o.x, l0), __shfl(o.y, l0), __shfl(o.z, l0));
+                const bool same = !valid || (o.x == e.x && o.y == e.y && o.z == e.z);                    // a common origin (no thin lens)
+                const f3 ax = fan_axis(mk(__shfl(d.x, l0), __shfl(d.y, l0), __shfl(d.z, l0)), mk(__shfl(d.x, l1), __shfl(d.y, l1), __shfl(d.z, l1)));
+                float md = valid ? __builtin_fmaf(d.z, ax.z, __builtin_fmaf(d.y, ax.y, d.x * ax.x)) : 1.0f;
+                if (!(md == md)) md = -1.0f;                                                             // a NaN direction: no cone
+#pragma unroll
+                for (int sft = 32; sft > 0; sft >>= 1) md = fminf(md, __shfl_xor(md, sft));
+                FanCone cone;
+                fan = fan_finish(e, ax, md, cone) && __ballot(!same) == 0ull;
+                if (fan) {
+                    for (int base = 0; base < a.G; base += 64) {
+                        const int p = base + (int)lane;
+                        bool meets = false;
+                        if (p < a.G) {
+                            const GeomRec *g = lg + p;
+                            const int ty = g->type;
+                            if (ty == 0 || ty == 1) meets = fan_meets(g->bmin, g->bmax, ty == 0, cone);
+                        }
+                        u64 m = __ballot(meets);
+                        while (m) {
+                            const uint32_t j = (uint32_t)__builtin_ctzll(m);
+                            m &= m - 1ull;
+                            bound_vs_group((uint32_t)base + j);
+                        }
+                    }
+                }
             }
+            // ---------------------------------------------------------------- the big primitives: every ray, wave-uniform index
+            if (!fan)
+                for (int k = 0; k < nbig; ++k) bound_vs_group((uint32_t)__builtin_amdgcn_readfirstlane((int)ld_big(k)));
             PT_WSTAT(25, (unsigned long long)nbig * nv);
             // ---------------------------------------------------------------- walk set-up
             // Walked: finite rays that start within `reach` of the grid (the others overflow their list on purpose).
@@ -346,7 +431,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
             if (valid && !sane) ncand0 = kListCap + 1u;
             PT_WSTAT(24, __popcll(__ballot(valid && !sane)));
             if (valid) wl[F_META * R + sid] = ncand0;                                      // candidate count while the pairs are worked off
-            GridWalk gw = grid_walk_begin(lga, o, d, cr.inv, valid && sane);
+            GridWalk gw;
+            gw.walking = false;
+            if (!fan) gw = grid_walk_begin(lga, o, d, cr.inv, valid && sane);
             const uint32_t max_trips = (uint32_t)__builtin_amdgcn_readfirstlane(lga.n[0] + lga.n[1] + lga.n[2]) + 2u;     // a walk takes at most n_x + n_y + n_z - 2 steps
             uint32_t trips = 0u;
             // ---------------------------------------------------------------- WALK / CELLS / BOUNDS under one dispatcher
@@ -372,11 +459,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
                         if (wb == 0ull || trips >= max_trips) { walk_left = false; break; }
                         trips++;
                         PT_WSTAT(2, 1); PT_WSTAT(3, __popcll(wb));
-                        uint32_t rec = 0u;
-                        if (gw.walking) rec = cells[grid_walk_cell(gw)];
-                        const bool emit = (rec >> 16) != 0u;
+                        uint32_t rec = BIG ? 0xFFFFFFFFu : 0u;
+                        if (gw.walking) rec = ld_cell(grid_walk_cell(gw));
+                        const bool emit = BIG ? rec != 0xFFFFFFFFu : (rec >> 16) != 0u;
                         const u64 eb = __ballot(emit);
-                        if (emit) bufA[nA + wave_rank(eb)] = sid | ((rec & 0xFFFFu) << 8) | (gw.emask << 21);  // the cell's first reference
+                        if (emit) bufA[nA + wave_rank(eb)] = sid | ((BIG ? rec : (rec & 0xFFFFu)) << Fm::kRefShift) | (gw.emask << Fm::kEmaskShift);  // the cell's first reference
                         nA += (uint32_t)__popcll(eb);
                         PT_WSTAT(4, __popcll(eb));
                         if (gw.walking) grid_walk_step(gw);
@@ -390,24 +477,26 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
                     PT_PHASE(3);
                     const uint32_t n = nA < 64u ? nA : 64u;
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    uint32_t e = 0u, ref = 0x4000u;
+                    uint32_t e = 0u, ref = BIG ? 0x40000000u : 0x4000u;
                     const bool evalid = lane < n;
                     if (evalid) {
                         e = bufA[nA - n + lane];
-                        ref = (uint32_t)refs[(e >> 8) & 0x1FFFu];
+                        if constexpr (BIG) ref = ld_ref32((e >> Fm::kRefShift) & Fm::kRefMask);
+                        else ref = (uint32_t)refs[(e >> Fm::kRefShift) & Fm::kRefMask];
                     }
                     nA -= n;
                     PT_WSTAT(5, 1); PT_WSTAT(6, n);
-                    const bool isnew = evalid && grid_ref_is_new(ref, e >> 21);
-                    const bool sph = (ref & 0x8000u) != 0u;
-                    const bool again = (ref & 0x4000u) == 0u;                              // (invalid lanes: `last` is set)
+                    const uint32_t rflags = BIG ? ref >> 24 : ref >> 8, rprim = BIG ? (ref & 0xFFFFFFu) : (ref & 0xFFu);
+                    const bool isnew = evalid && grid_flags_new(rflags, e >> Fm::kEmaskShift);
+                    const bool sph = (rflags & 0x80u) != 0u;
+                    const bool again = (rflags & 0x40u) == 0u;                             // (invalid lanes: `last` is set)
                     const u64 bb = __ballot(isnew && !sph), sb = __ballot(isnew && sph), gb = __ballot(again);
                     __builtin_amdgcn_wave_barrier();                                       // every entry is read before any is overwritten
                     if (isnew) {
                         const uint32_t pos = sph ? kBufC - 1u - (nCs + wave_rank(sb)) : nCb + wave_rank(bb);
-                        bufC[pos] = (e & 0xFFu) | ((ref & 0xFFu) << 8);
+                        bufC[pos] = (e & ((1u << Fm::kSidBits) - 1u)) | (rprim << 8);
                     }
-                    if (again) bufA[nA + wave_rank(gb)] = e + 0x100u;
+                    if (again) bufA[nA + wave_rank(gb)] = e + (1u << Fm::kRefShift);
                     nCb += (uint32_t)__popcll(bb); nCs += (uint32_t)__popcll(sb); nA += (uint32_t)__popcll(gb);
                     PT_WSTAT(9, __popcll(bb) + __popcll(sb));
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -440,10 +529,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
 #ifdef PT_CULL_STATS
                         atomicAdd(&g_wstats[14], 1ull);
 #endif
-                        if (pos < kListCap) {
-                            unsigned short *l16 = reinterpret_cast<unsigned short *>(&wl[(F_L0 + (pos >> 1)) * R + psid]) + (pos & 1u);
-                            *l16 = (unsigned short)((quant_tn(tn, qscale) << 8) | pp);
-                        }
+                        if (pos < kListCap) list_put(psid, pos, quant_tn<BIG>(tn, qscale), pp, !isb);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -502,20 +588,25 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
                 if (cnt > kListCap) {
                     if (ovhit >= 0) {
                         first_id = (uint32_t)ovhit; queued = true;
-                        wl[F_L0 * R + sid] = 0xFFFFFFFFu; wl[F_L1 * R + sid] = 0xFFFFFFFFu; wl[F_L2 * R + sid] = 0xFFFFFFFFu; wl[F_L3 * R + sid] = 0xFFFFFFFFu;
+                        tobox = lg[first_id].type == 1;
+#pragma unroll
+                        for (uint32_t k = 0; k < LW; ++k) wl[(F_L0 + k) * R + sid] = 0xFFFFFFFFu;
                     }
                 } else if (cnt != 0u) {
-                    uint32_t L[4] = {wl[F_L0 * R + sid], wl[F_L1 * R + sid], wl[F_L2 * R + sid], wl[F_L3 * R + sid]};
+                    uint32_t L[LW];
+#pragma unroll
+                    for (uint32_t k = 0; k < LW; ++k) L[k] = wl[(F_L0 + k) * R + sid];
                     uint32_t pos;
-                    const uint32_t key = select_next(L, 254u, pos);
-                    first_id = key & 0xFFu; queued = true;
-                    const uint32_t clr = (pos & 1u) ? 0xFFFF0000u : 0x0000FFFFu;           // the chosen entry leaves the list
-                    wl[(F_L0 + (pos >> 1)) * R + sid] = L[pos >> 1] | clr;
+                    const uint32_t key = select_next<BIG>(L, Fm::kQMax, pos);
+                    queued = true;
+                    if constexpr (BIG) { first_id = key & kBigIdMask; tobox = (key & kBigSphere) == 0u; }
+                    else { first_id = key & 0xFFu; tobox = lg[first_id].type == 1; }
+                    list_clear(sid, pos, L);                                               // the chosen entry leaves the list
                 }
                 if (queued) {
-                    wl[F_META * R + sid] = first_id | (pid << 19);                         // current candidate, no hit yet
+                    if constexpr (BIG) { wl[F_META * R + sid] = first_id | (pid << 24); wl[F_HIT * R + sid] = 0u; }     // current candidate, no hit yet
+                    else wl[F_META * R + sid] = first_id | (pid << 19);
                     wf[F_BEST * R + sid] = kInf;
-                    tobox = lg[first_id].type == 1;
                 }
             }
             {
@@ -548,8 +639,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
             if (isb) nbox -= cnt; else nsph -= cnt;
             PT_WSTAT(isb ? 16 : 18, 1); PT_WSTAT(isb ? 17 : 19, cnt);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            uint32_t sid = 0u, meta = 0u;
-            uint32_t L[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            uint32_t sid = 0u, meta = 0u, hitw = 0u;
+            uint32_t L[LW];
+#pragma unroll
+            for (uint32_t k = 0; k < LW; ++k) L[k] = 0xFFFFFFFFu;
             f3 o = mk(0, 0, 0), d = mk(0, 0, 1);
             float best = kInf;
             if (valid) {
@@ -557,14 +650,17 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
                 o = mk(wf[F_OX * R + sid], wf[F_OY * R + sid], wf[F_OZ * R + sid]);
                 d = mk(wf[F_DX * R + sid], wf[F_DY * R + sid], wf[F_DZ * R + sid]);
                 meta = wl[F_META * R + sid];
+                if constexpr (BIG) hitw = wl[F_HIT * R + sid];
                 best = wf[F_BEST * R + sid];
-                L[0] = wl[F_L0 * R + sid]; L[1] = wl[F_L1 * R + sid]; L[2] = wl[F_L2 * R + sid]; L[3] = wl[F_L3 * R + sid];
+#pragma unroll
+                for (uint32_t k = 0; k < LW; ++k) L[k] = wl[(F_L0 + k) * R + sid];
             }
             __builtin_amdgcn_wave_barrier();
-            const uint32_t j = meta & 0xFFu, pid = (meta >> 19) & 0xFFu;
-            bool has_hit = (meta & kMetaHasHit) != 0u;
-            uint32_t hit = (meta >> 8) & 0xFFu;
-            int face = (int)((meta >> 16) & 7u) - 1;
+            const uint32_t j = BIG ? (meta & kBigIdMask) : (meta & 0xFFu), pid = BIG ? (meta >> 24) : ((meta >> 19) & 0xFFu);
+            bool has_hit = BIG ? (hitw >> 31) != 0u : (meta & kMetaHasHit) != 0u;
+            uint32_t hit = BIG ? (hitw & kBigIdMask) : ((meta >> 8) & 0xFFu);
+            bool hit_box = BIG ? ((hitw >> 30) & 1u) != 0u : false;                   // (narrow: looked up in the LDS table)
+            int face = (int)((meta >> (BIG ? 21 : 16)) & 7u) - 1;
             bool won = false;
             f3 P = mk(0, 0, 0), N = mk(0, 0, 0);
             {
@@ -577,38 +673,43 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
                 }
                 // nearest-hit update of the reference loop: first strictly nearer wins, ties to the lower index
                 won = valid && depth > -PT_EPSILON && (has_hit ? (depth < best || (depth == best && j < hit)) : depth < kInf);
-                if (won) { best = depth; hit = j; face = fc; has_hit = true; }
+                if (won) { best = depth; hit = j; face = fc; has_hit = true; hit_box = isb; }
             }
             // the new best hit's point and normal wait in the payload record (an earlier winner's stay there otherwise)
             if (won) {
-                pay_st(pid, Q_HIT, P.x, P.y, P.z, __uint_as_float(hit | ((uint32_t)(face + 1) << 8)));
+                pay_st(pid, Q_HIT, P.x, P.y, P.z, __uint_as_float(hit | ((uint32_t)(face + 1) << (BIG ? 24 : 8))));
                 if (!isb) pay_st(pid, Q_NRM, N.x, N.y, N.z, 0.0f);
             }
             // the next candidate that could still win or tie: key distance not beyond the best hit (conservative: one step of slack)
             PT_PHASE(7);
             uint32_t npos = 0u;
-            uint32_t qmax = 254u;
+            uint32_t qmax = Fm::kQMax;
             if (has_hit) {
-                const float lim = fminf((best + slack_max) * qscale, 253.0f);
+                const float lim = fminf((best + slack_max) * qscale, (float)(Fm::kQMax - 1u));
                 qmax = (uint32_t)lim + 1u;
             }
-            const uint32_t nkey = valid ? select_next(L, qmax, npos) : 0xFFFFu;
-            const bool more = nkey != 0xFFFFu;
+            const uint32_t nkey = valid ? select_next<BIG>(L, qmax, npos) : Fm::kEmpty;
+            const bool more = nkey != Fm::kEmpty;
             const bool done = valid && !more;
             bool nbx = false;
             if (more) {
-                const uint32_t nid = nkey & 0xFFu;
-                const uint32_t clr = (npos & 1u) ? 0xFFFF0000u : 0x0000FFFFu;
-                wl[(F_L0 + (npos >> 1)) * R + sid] = L[npos >> 1] | clr;
-                wl[F_META * R + sid] = nid | (hit << 8) | ((uint32_t)(face + 1) << 16) | (pid << 19) | (has_hit ? kMetaHasHit : 0u);
+                const uint32_t nid = BIG ? (nkey & kBigIdMask) : (nkey & 0xFFu);
+                list_clear(sid, npos, L);
+                if constexpr (BIG) {
+                    wl[F_META * R + sid] = nid | ((uint32_t)(face + 1) << 21) | (pid << 24);
+                    wl[F_HIT * R + sid] = hit | (hit_box ? 1u << 30 : 0u) | (has_hit ? 1u << 31 : 0u);
+                    nbx = (nkey & kBigSphere) == 0u;
+                } else {
+                    wl[F_META * R + sid] = nid | (hit << 8) | ((uint32_t)(face + 1) << 16) | (pid << 19) | (has_hit ? kMetaHasHit : 0u);
+                    nbx = lg[nid].type == 1;
+                }
                 wf[F_BEST * R + sid] = best;
-                nbx = lg[nid].type == 1;
             }
             // a finished ray leaves its slot: with a hit, its payload record waits for the shading of that TYPE of primitive
             const bool toshade = done && has_hit;
             bool shb = false;
             if (toshade) {
-                shb = lg[hit].type == 1;
+                if constexpr (BIG) shb = hit_box; else shb = lg[hit].type == 1;
             }
             PT_WSTAT(20, __popcll(__ballot(toshade))); PT_WSTAT(21, __popcll(__ballot(done)));
             PT_WSTAT(22, __popcll(__ballot(more))); PT_WSTAT(23, __popcll(__ballot(more && won)));
@@ -658,8 +759,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
                 P = mk(__uint_as_float(qc.x), __uint_as_float(qc.y), __uint_as_float(qc.z)); hf = qc.w;
                 if (!hbx) { const u32x4 qd = pay_ld(pid, Q_NRM); N = mk(__uint_as_float(qd.x), __uint_as_float(qd.y), __uint_as_float(qd.z)); }
             }
-            const uint32_t hit = hf & 0xFFu;
-            const int face = (int)((hf >> 8) & 7u) - 1;
+            const uint32_t hit = BIG ? (hf & 0xFFFFFFu) : (hf & 0xFFu);
+            const int face = (int)((hf >> (BIG ? 24 : 8)) & 7u) - 1;
             bool alive = false;
             if (valid) {
                 const uint32_t slot = a.batch > 1u ? pv >> 24 : 0u, pixel = pv & a.pix_mask;
@@ -754,40 +855,49 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
 
 // ------------------------------------------------------------------ host side ---------
 namespace {
-struct WideShape { int waves, slots, payload; };
-// variant -> block shape.  One block per CU; the waves share the CU's LDS: tables + grid + waves x (12 x slots + the byte lists + the
-// two pair buffers).  3: what variant 0 falls back to when a large grid leaves less room.
-constexpr WideShape kShapes[4] = {{16, 112, 240}, {12, 144, 256}, {8, 192, 256}, {16, 80, 208}};
+struct WideShape { int waves, slots, payload; bool big; };
+// shape -> block.  One block per CU; the waves share the CU's LDS: tables + grid + waves x (slot fields x slots + the byte lists + the
+// two pair buffers).  0: narrow default; 1: narrow, what 0 falls back to when a large grid leaves less room; 2, 3: wide ids (more
+// than 256 primitives: 17 slot fields, no geometry table in LDS) with more slots or more room for the grid
+constexpr WideShape kShapes[4] = {{16, 112, 240, false}, {16, 80, 208, false}, {16, 96, 224, true}, {16, 80, 208, true}};
 
-template <int WAVES, int R, int NP>
-const void *wide_fn() { return reinterpret_cast<const void *>(&k_path_w<WAVES, R, NP>); }
 const void *wide_fn_of(int v) {
-    return v == 1 ? wide_fn<12, 144, 256>() : v == 2 ? wide_fn<8, 192, 256>() : v == 3 ? wide_fn<16, 80, 208>() : wide_fn<16, 112, 240>();
+    switch (v) {
+    case 1: return reinterpret_cast<const void *>(&k_path_w<16, 80, 208, false>);
+    case 2: return reinterpret_cast<const void *>(&k_path_w<16, 96, 224, true>);
+    case 3: return reinterpret_cast<const void *>(&k_path_w<16, 80, 208, true>);
+    default: return reinterpret_cast<const void *>(&k_path_w<16, 112, 240, false>);
+    }
 }
-int clamp_variant(int v) { return v < 0 || v > 3 ? 0 : v; }
+uint32_t shape_lds(const WideShape &s, int G, int M, uint32_t grid_bytes) {
+    const uint32_t fields = s.big ? 17u : 12u;
+    return tables_bytes(G, M, !s.big) + grid_bytes +
+           (uint32_t)s.waves * (fields * (uint32_t)s.slots + (2u * (uint32_t)s.slots + 2u * (uint32_t)s.payload) / 4u + kBufA + kBufC) * 4u;
+}
 }  // namespace
 
-hipError_t wide_setup(int variant, int G, int M, uint32_t grid_bytes, WideLayout *out) {
-    const int v = clamp_variant(variant);
-    const WideShape s = kShapes[v];
-    const uint32_t lds = tables_bytes(G, M, true) + grid_bytes +
-                         (uint32_t)s.waves * (12u * (uint32_t)s.slots + (2u * (uint32_t)s.slots + 2u * (uint32_t)s.payload) / 4u + kBufA + kBufC) * 4u;
+// LDS a shape needs beside `grid_bytes` of grid (0: the grid stays in global memory; wide shapes only)
+uint32_t wide_lds_bytes(int shape, int G, int M, uint32_t grid_bytes) { return shape_lds(kShapes[shape & 3], G, M, grid_bytes); }
+
+hipError_t wide_setup(int shape, int G, int M, uint32_t grid_bytes, WideLayout *out) {
+    const WideShape s = kShapes[shape & 3];
+    const uint32_t lds = shape_lds(s, G, M, grid_bytes);
     out->waves_per_block = (uint32_t)s.waves;
     out->slots_per_wave = (uint32_t)s.slots;
     out->payload_per_wave = (uint32_t)s.payload;
     out->stack_slots = (uint32_t)((s.payload + 64 * (int)kWalkBins + 63) / 64 * 64);
     out->lds_bytes = lds;
-    if (lds > 160u * 1024u) return hipErrorInvalidValue;        // the tables leave no room for this shape (the caller tries the next)
-    return hipFuncSetAttribute(wide_fn_of(v), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (lds > 160u * 1024u) return hipErrorInvalidValue;        // no room for this shape (the caller tries the next)
+    return hipFuncSetAttribute(wide_fn_of(shape & 3), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-void wide_launch(int variant, int grid, uint32_t lds, hipStream_t st, const SegArgs &a, const PathArgs &pa, const GridArgs &ga,
+void wide_launch(int shape, int grid, uint32_t lds, hipStream_t st, const SegArgs &a, const PathArgs &pa, const GridArgs &ga,
                  const GeomRec *g, const MatRec *m, const FaceFrame *frames) {
-    switch (clamp_variant(variant)) {
-    case 1: hipLaunchKernelGGL((k_path_w<12, 144, 256>), dim3(grid), dim3(12 * 64), lds, st, a, pa, ga, g, m, frames); break;
-    case 2: hipLaunchKernelGGL((k_path_w<8, 192, 256>), dim3(grid), dim3(8 * 64), lds, st, a, pa, ga, g, m, frames); break;
-    case 3: hipLaunchKernelGGL((k_path_w<16, 80, 208>), dim3(grid), dim3(16 * 64), lds, st, a, pa, ga, g, m, frames); break;
-    default: hipLaunchKernelGGL((k_path_w<16, 112, 240>), dim3(grid), dim3(16 * 64), lds, st, a, pa, ga, g, m, frames); break;
+    switch (shape & 3) {
+    case 1: hipLaunchKernelGGL((k_path_w<16, 80, 208, false>), dim3(grid), dim3(16 * 64), lds, st, a, pa, ga, g, m, frames); break;
+    case 2: hipLaunchKernelGGL((k_path_w<16, 96, 224, true>), dim3(grid), dim3(16 * 64), lds, st, a, pa, ga, g, m, frames); break;
+    case 3: hipLaunchKernelGGL((k_path_w<16, 80, 208, true>), dim3(grid), dim3(16 * 64), lds, st, a, pa, ga, g, m, frames); break;
+    default: hipLaunchKernelGGL((k_path_w<16, 112, 240, false>), dim3(grid), dim3(16 * 64), lds, st, a, pa, ga, g, m, frames); break;
     }
 }
 

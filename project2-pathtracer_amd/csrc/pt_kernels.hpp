@@ -709,6 +709,7 @@ struct GridArgs {
     uint32_t blob_bytes;             // multiple of 16
     const unsigned char *blob;       // device copy
     uint32_t bin1, bin2;             // survivors wait for their next bounce sorted by the length of their walk in cells: <= bin1, <= bin2, longer
+    uint32_t in_lds;                 // wide references only: the blob is staged in LDS (it fits beside the waves' regions); 0: read from `blob`
 };
 constexpr uint32_t kWalkBins = 3;
 
@@ -806,6 +807,52 @@ __host__ __device__ __forceinline__ bool grid_walk_sane(const GridArgs &ga, f3 o
            fabsf(d.x) <= 4.0f && fabsf(d.y) <= 4.0f && fabsf(d.z) <= 4.0f;
 }
 
+// ---- camera groups of k_path_w: one cone for the 64 rays, one pass over the primitives' bounds --------------------------
+// The camera rays of a FRESH group share their origin (pinhole, with or without jitter) and fan out over a degree or two.  Instead
+// of 64 walks through the grid, the wave (lane = one primitive) tests every primitive's bound against the CONE of the group --
+// apex = the common origin, axis = the normalised sum of the first and the last ray's direction, half angle = the largest angle any
+// of the 64 directions makes with the axis (measured, so the reference's normalize(R) quirk and jitter are covered as they are) --
+// and only the few primitives the cone meets have their bounds tested by the rays themselves (wave-uniform index, like the big
+// primitives).  The cone test is cull-side arithmetic: it only has to be a superset of what any ray of the group can hit, and it
+// is, with margins of 1e-4 of the distances involved (float error: 1e-6) -- checked on the host by tests/test_grid_cpu.py through
+// pt_debug_fan_probe, which runs these very functions.
+struct FanCone { f3 apex, axis; float cs, sn; };      // cos / sin of the (loosened) half angle
+__host__ __device__ __forceinline__ f3 fan_axis(f3 d_first, f3 d_last) {
+    const f3 s = mk(d_first.x + d_last.x, d_first.y + d_last.y, d_first.z + d_last.z);
+    const float n2 = __builtin_fmaf(s.z, s.z, __builtin_fmaf(s.y, s.y, s.x * s.x));
+    const float inv = 1.0f / __builtin_sqrtf(n2 > 1e-30f ? n2 : 1e-30f);
+    return mk(s.x * inv, s.y * inv, s.z * inv);
+}
+// `min_dot` = the smallest dot(direction, axis) over the group's rays.  False: the fan is too wide to be worth a cone (or not finite)
+__host__ __device__ __forceinline__ bool fan_finish(f3 apex, f3 axis, float min_dot, FanCone &c) {
+    c.apex = apex; c.axis = axis;
+    const float cs = min_dot * (1.0f - 1e-5f) - 1e-5f;           // a larger angle
+    c.cs = cs;
+    c.sn = __builtin_sqrtf(fmaxf(1.0f - cs * cs, 0.0f));
+    return cs > 0.9f && cs <= 1.0f;                               // wider than 25 degrees (a group that wraps from one pixel row to the next): no cone; (NaN: false)
+}
+// may a ray of the cone meet the bound?  sphere: centre bmin.xyz, radius bmax[3]; cube: the sphere around its AABB
+__host__ __device__ __forceinline__ bool fan_meets(const float *bmin, const float *bmax, bool sphere, const FanCone &c) {
+    f3 ctr;
+    float r;
+    if (sphere) { ctr = mk(bmin[0], bmin[1], bmin[2]); r = bmax[3]; }
+    else {
+        ctr = mk(0.5f * (bmin[0] + bmax[0]), 0.5f * (bmin[1] + bmax[1]), 0.5f * (bmin[2] + bmax[2]));
+        const f3 h = mk(bmax[0] - ctr.x, bmax[1] - ctr.y, bmax[2] - ctr.z);
+        r = __builtin_sqrtf(__builtin_fmaf(h.z, h.z, __builtin_fmaf(h.y, h.y, h.x * h.x))) * 1.000001f;
+    }
+    const f3 v = mk(ctr.x - c.apex.x, ctr.y - c.apex.y, ctr.z - c.apex.z);
+    const float n2 = __builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x));
+    const float s = __builtin_fmaf(v.z, c.axis.z, __builtin_fmaf(v.y, c.axis.y, v.x * c.axis.x));
+    const f3 w = mk(__builtin_fmaf(-s, c.axis.x, v.x), __builtin_fmaf(-s, c.axis.y, v.y), __builtin_fmaf(-s, c.axis.z, v.z));   // v minus its axial part: no cancellation in p
+    const float p = __builtin_sqrtf(__builtin_fmaf(w.z, w.z, __builtin_fmaf(w.y, w.y, w.x * w.x)));
+    const float rr = __builtin_fmaf(1e-4f, r + __builtin_sqrtf(n2), r) + 1e-30f;
+    // distance of the centre from the solid cone >= p cos - s sin (equality beside the cone's flank; behind the apex the true distance
+    // is |v|, which is larger): outside only if that exceeds the radius.  A false comparison (NaN) keeps the primitive.
+    return !(__builtin_fmaf(p, c.cs, -(s * c.sn)) > rr);
+}
+constexpr int kFanMaxPrims = 2048;       // beyond this many primitives the pass over all bounds costs more than the walks it replaces
+
 __host__ __device__ inline uint32_t p_cursor_offset(int G, int M) { return q_lds_offset(G, M); }
 __host__ __device__ inline uint32_t p_queue_offset(int G, int M) { return p_cursor_offset(G, M); }
 __host__ __device__ inline uint32_t p_lds_bytes(int G, int M, uint32_t cap) { return p_queue_offset(G, M) + (uint32_t)kWaves * cap * kPFields * 4u; }
@@ -877,10 +924,12 @@ void path_launch(bool mesh, bool nee, int cap, int grid, uint32_t lds_bytes, hip
                  const GeomRec *geoms, const MatRec *mats, const QTables &qt);
 constexpr uint32_t kNeeExtraFields = 9;  // k_path_q<NEE>: words a stack / parked record holds beyond the common ones
 
-// k_path_w (pt_k_wide.hip): `variant` picks the block shape; the layout says what it needs
+// k_path_w (pt_k_wide.hip): `shape` 0 / 1 = narrow ids (33..256 primitives, tables in LDS), 2 / 3 = wide ids (more than 256
+// primitives, geometry gathered from global memory); the layout says what a shape needs
 struct WideLayout { uint32_t waves_per_block, slots_per_wave, payload_per_wave, stack_slots, lds_bytes; };
-hipError_t wide_setup(int variant, int G, int M, uint32_t grid_bytes, WideLayout *out);
-void wide_launch(int variant, int grid, uint32_t lds_bytes, hipStream_t stream, const SegArgs &a, const PathArgs &pa, const GridArgs &ga,
+uint32_t wide_lds_bytes(int shape, int G, int M, uint32_t grid_bytes);
+hipError_t wide_setup(int shape, int G, int M, uint32_t grid_bytes, WideLayout *out);
+void wide_launch(int shape, int grid, uint32_t lds_bytes, hipStream_t stream, const SegArgs &a, const PathArgs &pa, const GridArgs &ga,
                  const GeomRec *geoms, const MatRec *mats, const FaceFrame *frames);
 
 void fold_launch(hipStream_t stream, const FoldArgs &f);

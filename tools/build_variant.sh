@@ -10,5 +10,5 @@ SRC=${VARIANT_SRC:-csrc}
 mkdir -p build/variants
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math \
       -fno-slp-vectorize -w -shared $SRC/pt_api.hip $SRC/pt_k_seg.hip $SRC/pt_k_queue.hip $SRC/pt_k_path.hip $SRC/pt_k_wide.hip \
-      $SRC/pt_k_misc.hip $SRC/pt_scene.cpp $SRC/pt_build.cpp "$@" -o build/variants/$TAG.so
+      $SRC/pt_k_misc.hip $SRC/pt_scene.cpp $( [ -f $SRC/pt_build.cpp ] && echo $SRC/pt_build.cpp ) "$@" -o build/variants/$TAG.so
 echo built build/variants/$TAG.so

@@ -10,6 +10,7 @@ These are the build's own files (typed from parameter tables below, no comments,
   cornell_c1.txt         config 1: RES 400 400, ITERATIONS 1
   cornell_mirror.txt     config 3: 1920x1080, materials 3,4,6 are perfect mirrors (REFL 1)
   random256.txt          config 4: Cornell shell + 250 random spheres/cubes, seed 565, 1920x1080
+  random1024.txt         the same shell + 1 018 smaller spheres/cubes, seed 566: more than 256 primitives (not a BASELINE configuration)
   cornell_glass_4k.txt   config 5: 3840x2160, sphere 5 uses the glass material (REFR 1, IOR 2.2)
   cornell_mesh.txt       GEOMTYPE MESH (the reference only declares it): Cornell shell + light + three `*.obj` objects
                          -- a 320-triangle icosphere (diffuse), a quad-faced torus (mirror) and a glass tetrahedron,
@@ -97,7 +98,7 @@ class MinStd:
         return lo + (hi - lo) * ((self.x - 1) / 2147483648.0)
 
 
-def random256(seed=565, extra=250):
+def random256(seed=565, extra=250, size=(0.2, 0.8)):
     mats = [
         CORNELL_MATERIALS[0], CORNELL_MATERIALS[1], CORNELL_MATERIALS[2],
         ((1, 1, 1), 0, (.9, .9, .9), 1, 0, 0, 0, (0, 0, 0), 0, 0),          # 3 mirror
@@ -110,7 +111,7 @@ def random256(seed=565, extra=250):
     rng = MinStd(seed)
     for i in range(extra):
         c = (round(rng.u(-4.5, 4.5), 3), round(rng.u(0.5, 9.0), 3), round(rng.u(-4.5, 4.5), 3))
-        s = round(rng.u(0.2, 0.8), 3)
+        s = round(rng.u(size[0], size[1]), 3)
         if i & 1:
             rot = (round(rng.u(0, 360), 2), round(rng.u(0, 360), 2), round(rng.u(0, 360), 2))
             objs.append(("cube", i % 7, c, rot, (s, s, s)))
@@ -215,6 +216,9 @@ def main():
                 "renders/cornell_mirror.bmp")
     mats, objs = random256()
     write_scene(os.path.join(out, "random256.txt"), mats, objs, (1920, 1080), 1000, "renders/random256.bmp", frames=1)
+    # beyond 256 primitives (the reference's loop takes any count): the same room with 1 018 smaller spheres / cubes
+    mats, objs = random256(seed=566, extra=1018, size=(0.12, 0.5))
+    write_scene(os.path.join(out, "random1024.txt"), mats, objs, (1920, 1080), 1000, "renders/random1024.bmp", frames=1)
     glass = list(CORNELL_OBJECTS)
     glass[5] = ("sphere", 5, (0, 2, 0), (0, 180, 0), (3, 3, 3))
     write_scene(os.path.join(out, "cornell_glass_4k.txt"), CORNELL_MATERIALS, glass, (3840, 2160), 1000,
