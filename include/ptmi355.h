@@ -254,9 +254,10 @@ int  pt_debug_sincos(pt_context *ctx, int n, const float *a, float *s, float *c)
  * of the uploaded scene for n float seeds (the reference's light-sampling helpers; no call sites there) */
 int  pt_debug_light_points(pt_context *ctx, int geom, int n, const float *seeds, float *out3);
 
-/* The spatial index of the whole-path kernel for 33..256 primitives, probed WITHOUT a device: builds the uniform grid of
- * the scene as pt_upload_scene does and walks nrays rays (6 floats each: origin, direction) on the host with the kernel's
- * own walk functions.  out_sets: nrays x 8 words, bit p of a ray = primitive p gets its bound tested for that ray (every
+/* The spatial index of the whole-path kernel for more than 32 primitives (k_path_w), probed WITHOUT a device: builds the uniform
+ * grid of the scene as pt_upload_scene does (16-bit references up to 256 primitives, 32-bit ones beyond) and walks nrays rays (6
+ * floats each: origin, direction) on the host with the kernel's own walk functions.  out_sets: nrays x max(8, ceil(ngeoms / 32))
+ * words, bit p of a ray = primitive p gets its bound tested for that ray (every
  * bit for a ray the kernel would not walk: it takes the reference loop).  out_info: [0] cells [1] references [2] big
  * primitives [3] primitives listed twice for a ray (must be 0) [4] rays not walked [5..7] cells per axis [8] mean and
  * [9] longest walk in cells [10] non-empty cells and [11] listed primitives per ray x 100 [12] bytes of LDS [13] [14] the walk
@@ -264,6 +265,11 @@ int  pt_debug_light_points(pt_context *ctx, int geom, int n, const float *seeds,
  * behind that sorting (cells).  out_info holds 24 words. */
 int  pt_debug_grid_probe(const pt_geom *geoms, int ngeoms, int density, const float *rays, int nrays,
                          uint32_t *out_sets, uint32_t *out_info);
+/* The cone test k_path_w gives a group of 64 camera rays instead of 64 grid walks, on the host: nfans x 64 rays (6 floats each;
+ * a fan = 64 rays with a common origin).  out_sets: nfans x max(8, ceil(ngeoms / 32)) words, bit p = the cone of the fan meets
+ * primitive p's bound, i.e. the fan's rays test that bound (every bit when the fan gets no cone -- no common origin, a half angle above
+ * 5.7 degrees, not finite: the kernel then walks the grid).  out_info[0] = fans that got a cone; out_info holds 4 words. */
+int  pt_debug_fan_probe(const pt_geom *geoms, int ngeoms, const float *rays, int nfans, uint32_t *out_sets, uint32_t *out_info);
 
 /* ---- host-side scene I/O (no GPU needed; src/scene.cpp grammar, src/image.cpp output) ---- */
 

@@ -113,6 +113,8 @@ def lib():
         L.pt_debug_path_shape.argtypes = [vp, C.POINTER(C.c_uint)]
     if hasattr(L, "pt_debug_grid_probe"):      # (absent from builds of older commits that tools/ab_lib.sh compares against)
         L.pt_debug_grid_probe.argtypes = [C.POINTER(Geom), C.c_int, C.c_int, fp, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    if hasattr(L, "pt_debug_fan_probe"):
+        L.pt_debug_fan_probe.argtypes = [C.POINTER(Geom), C.c_int, fp, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.pt_scene_load.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.pt_scene_free.argtypes = [vp]; L.pt_scene_free.restype = None
     L.pt_scene_counts.argtypes = [vp, ip, ip, ip, ip]
@@ -130,7 +132,7 @@ EXPORTS = [
     "pt_abi_version", "pt_last_error", "pt_config_default", "pt_device_count", "pt_create", "pt_destroy",
     "pt_upload_scene", "pt_set_meshes", "pt_scene_mesh_count", "pt_scene_mesh", "pt_set_image", "pt_bind_device_image", "pt_get_image", "pt_get_rows", "pt_gather_rows_peer", "pt_render", "pt_sync",
     "pt_display", "pt_set_profiling", "pt_get_stats", "pt_reset_stats", "pt_get_resolution", "pt_debug_primary_hits",
-    "pt_debug_trace_pool", "pt_debug_set_turn_limit", "pt_debug_path_shape", "pt_debug_rng_from_thread", "pt_debug_hemisphere", "pt_debug_sincos", "pt_debug_light_points", "pt_debug_grid_probe",
+    "pt_debug_trace_pool", "pt_debug_set_turn_limit", "pt_debug_path_shape", "pt_debug_rng_from_thread", "pt_debug_hemisphere", "pt_debug_sincos", "pt_debug_light_points", "pt_debug_grid_probe", "pt_debug_fan_probe",
     "pt_scene_load", "pt_scene_free", "pt_scene_counts", "pt_scene_image_name", "pt_scene_flatten",
     "pt_scene_object_matrices", "pt_build_transform", "pt_image_to_u8", "pt_image_save",
 ]
@@ -360,6 +362,19 @@ def grid_probe(geoms, rays, density=0):
     names = ["cells", "refs", "big", "duplicates", "unwalked", "nx", "ny", "nz", "mean_walk", "longest_walk",
              "cells_per_ray_x100", "listed_per_ray_x100", "lds_bytes", "bin1", "bin2", "length_estimate_worst", "length_estimate_mean_error_x100"]
     return sets, {k: int(v) for k, v in zip(names, info)}
+
+
+def fan_probe(geoms, rays):
+    """The cone test of k_path_w's camera groups on the host (no device): rays[nfans, 64, 6] -> (sets[nfans, >= 256] bool: the
+    fan's rays test primitive p's bound, fans_with_a_cone)."""
+    import numpy as np
+    rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 64, 6)
+    n = rays.shape[0]
+    nwords = max(8, (len(geoms) + 31) // 32)
+    words = np.zeros((n, nwords), dtype=np.uint32)
+    info = np.zeros(4, dtype=np.uint32)
+    _check(lib().pt_debug_fan_probe(geoms, len(geoms), _fp(rays), n, words.ctypes.data_as(C.POINTER(C.c_uint32)), info.ctypes.data_as(C.POINTER(C.c_uint32))))
+    return np.unpackbits(words.view(np.uint8), axis=1, bitorder="little").astype(bool), int(info[0])
 
 
 def build_transform(t, r, s):

@@ -525,18 +525,20 @@ int fan_probe(const pt_geom *geoms, int G, const float *rays, int nfans, uint32_
         const float *r = rays + (size_t)f * 64 * 6;
         uint32_t *set = out_sets + (size_t)f * words;
         const f3 e = mk(r[0], r[1], r[2]);
-        const f3 ax = fan_axis(mk(r[3], r[4], r[5]), mk(r[63 * 6 + 3], r[63 * 6 + 4], r[63 * 6 + 5]));
-        float md = 1.0f;
+        const f3 df = mk(r[3], r[4], r[5]), dl = mk(r[63 * 6 + 3], r[63 * 6 + 4], r[63 * 6 + 5]);
+        const f3 ax = fan_axis(df, dl), nr = fan_normal(df, dl);
+        float md = 1.0f, mo = 0.0f;
         bool same = true;
         for (int l = 0; l < 64; ++l) {
             const float *q = r + 6 * l;
-            float dt = __builtin_fmaf(q[5], ax.z, __builtin_fmaf(q[4], ax.y, q[3] * ax.x));
-            if (!(dt == dt)) dt = -1.0f;
-            md = std::fmin(md, dt);
+            const float dt = __builtin_fmaf(q[5], ax.z, __builtin_fmaf(q[4], ax.y, q[3] * ax.x));
+            const float of = std::fabs(__builtin_fmaf(q[5], nr.z, __builtin_fmaf(q[4], nr.y, q[3] * nr.x)));
+            if (!(dt == dt) || !(of == of)) { md = -1.0f; continue; }
+            md = std::fmin(md, dt); mo = std::fmax(mo, of);
             same = same && q[0] == e.x && q[1] == e.y && q[2] == e.z;
         }
         FanCone cone;
-        if (!(fan_finish(e, ax, md, cone) && same)) { for (size_t k = 0; k < words; ++k) set[k] = 0xFFFFFFFFu; continue; }
+        if (!(fan_finish(e, ax, md, nr, mo, cone) && same)) { for (size_t k = 0; k < words; ++k) set[k] = 0xFFFFFFFFu; continue; }
         cones++;
         for (size_t k = 0; k < words; ++k) set[k] = 0u;
         for (int p = 0; p < G; ++p)

@@ -391,17 +391,19 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
             // ---------------------------------------------------------------- camera rays: ONE cone for the group instead of 64 walks
             // (pt_kernels.hpp, fan_*): lane = one primitive, its bound against the cone; the few it meets are tested by the rays.
             bool fan = false;
-            if (PT_FAN && act == 3 && a.G <= kFanMaxPrims) {
+            if (PT_FAN && !BIG && act == 3) {       // (wide ids: the pass over every bound is a pass over global memory -- 1.54 -> 1.61 ms/step on 1 024 primitives: the walks stay)
                 const int l0 = (int)__builtin_ctzll(vb), l1 = 63 - (int)__builtin_clzll(vb);            // (a FRESH group has a valid lane)
                 const f3 e = mk(__shfl(o.x, l0), __shfl(o.y, l0), __shfl(o.z, l0));
                 const bool same = !valid || (o.x == e.x && o.y == e.y && o.z == e.z);                    // a common origin (no thin lens)
-                const f3 ax = fan_axis(mk(__shfl(d.x, l0), __shfl(d.y, l0), __shfl(d.z, l0)), mk(__shfl(d.x, l1), __shfl(d.y, l1), __shfl(d.z, l1)));
+                const f3 df = mk(__shfl(d.x, l0), __shfl(d.y, l0), __shfl(d.z, l0)), dl = mk(__shfl(d.x, l1), __shfl(d.y, l1), __shfl(d.z, l1));
+                const f3 ax = fan_axis(df, dl), nr = fan_normal(df, dl);
                 float md = valid ? __builtin_fmaf(d.z, ax.z, __builtin_fmaf(d.y, ax.y, d.x * ax.x)) : 1.0f;
-                if (!(md == md)) md = -1.0f;                                                             // a NaN direction: no cone
+                float mo = valid ? fabsf(__builtin_fmaf(d.z, nr.z, __builtin_fmaf(d.y, nr.y, d.x * nr.x))) : 0.0f;
+                if (!(md == md) || !(mo == mo)) md = -1.0f;                                              // a NaN direction: no cone
 #pragma unroll
-                for (int sft = 32; sft > 0; sft >>= 1) md = fminf(md, __shfl_xor(md, sft));
+                for (int sft = 32; sft > 0; sft >>= 1) { md = fminf(md, __shfl_xor(md, sft)); mo = fmaxf(mo, __shfl_xor(mo, sft)); }
                 FanCone cone;
-                fan = fan_finish(e, ax, md, cone) && __ballot(!same) == 0ull;
+                fan = fan_finish(e, ax, md, nr, mo, cone) && __ballot(!same) == 0ull;
                 if (fan) {
                     for (int base = 0; base < a.G; base += 64) {
                         const int p = base + (int)lane;

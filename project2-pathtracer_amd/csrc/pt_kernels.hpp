@@ -816,20 +816,35 @@ __host__ __device__ __forceinline__ bool grid_walk_sane(const GridArgs &ga, f3 o
 // primitives).  The cone test is cull-side arithmetic: it only has to be a superset of what any ray of the group can hit, and it
 // is, with margins of 1e-4 of the distances involved (float error: 1e-6) -- checked on the host by tests/test_grid_cpu.py through
 // pt_debug_fan_probe, which runs these very functions.
-struct FanCone { f3 apex, axis; float cs, sn; };      // cos / sin of the (loosened) half angle
+struct FanCone { f3 apex, axis; float cs, sn; f3 nrm; float so; };   // cos / sin of the (loosened) half angle; the fan's plane through the
+                                                                    // apex (unit normal) and the sine of the largest angle a ray leaves it by
 __host__ __device__ __forceinline__ f3 fan_axis(f3 d_first, f3 d_last) {
     const f3 s = mk(d_first.x + d_last.x, d_first.y + d_last.y, d_first.z + d_last.z);
     const float n2 = __builtin_fmaf(s.z, s.z, __builtin_fmaf(s.y, s.y, s.x * s.x));
     const float inv = 1.0f / __builtin_sqrtf(n2 > 1e-30f ? n2 : 1e-30f);
     return mk(s.x * inv, s.y * inv, s.z * inv);
 }
-// `min_dot` = the smallest dot(direction, axis) over the group's rays.  False: the fan is too wide to be worth a cone (or not finite)
-__host__ __device__ __forceinline__ bool fan_finish(f3 apex, f3 axis, float min_dot, FanCone &c) {
-    c.apex = apex; c.axis = axis;
+// the plane the group's rays lie in, nearly (a pixel row: the first and the last direction span it; one ray: any plane through it)
+__host__ __device__ __forceinline__ f3 fan_normal(f3 d_first, f3 d_last) {
+    f3 n = mk(d_first.y * d_last.z - d_first.z * d_last.y, d_first.z * d_last.x - d_first.x * d_last.z, d_first.x * d_last.y - d_first.y * d_last.x);
+    float n2 = __builtin_fmaf(n.z, n.z, __builtin_fmaf(n.y, n.y, n.x * n.x));
+    if (!(n2 > 1e-12f)) {                                    // parallel directions: a normal of the first one
+        const f3 u = fabsf(d_first.x) < 0.6f ? mk(1.0f, 0.0f, 0.0f) : mk(0.0f, 1.0f, 0.0f);
+        n = mk(d_first.y * u.z - d_first.z * u.y, d_first.z * u.x - d_first.x * u.z, d_first.x * u.y - d_first.y * u.x);
+        n2 = __builtin_fmaf(n.z, n.z, __builtin_fmaf(n.y, n.y, n.x * n.x));
+    }
+    const float inv = 1.0f / __builtin_sqrtf(n2 > 1e-30f ? n2 : 1e-30f);
+    return mk(n.x * inv, n.y * inv, n.z * inv);
+}
+// `min_dot` = the smallest dot(direction, axis) over the group's rays, `max_off` = the largest |dot(direction, normal)|.
+// False: the fan is too wide to be worth a cone (or not finite)
+__host__ __device__ __forceinline__ bool fan_finish(f3 apex, f3 axis, float min_dot, f3 normal, float max_off, FanCone &c) {
+    c.apex = apex; c.axis = axis; c.nrm = normal;
+    c.so = max_off * 1.0001f + 1e-5f;                            // (directions are unit to 1e-6)
     const float cs = min_dot * (1.0f - 1e-5f) - 1e-5f;           // a larger angle
     c.cs = cs;
     c.sn = __builtin_sqrtf(fmaxf(1.0f - cs * cs, 0.0f));
-    return cs > 0.9f && cs <= 1.0f;                               // wider than 25 degrees (a group that wraps from one pixel row to the next): no cone; (NaN: false)
+    return cs > 0.995f && cs <= 1.0f;                             // half angle above 5.7 degrees (a group that wraps from one pixel row to the next, a frame a few hundred pixels wide): no cone -- it would meet too much of the scene; (NaN: false)
 }
 // may a ray of the cone meet the bound?  sphere: centre bmin.xyz, radius bmax[3]; cube: the sphere around its AABB
 __host__ __device__ __forceinline__ bool fan_meets(const float *bmin, const float *bmax, bool sphere, const FanCone &c) {
@@ -849,9 +864,13 @@ __host__ __device__ __forceinline__ bool fan_meets(const float *bmin, const floa
     const float rr = __builtin_fmaf(1e-4f, r + __builtin_sqrtf(n2), r) + 1e-30f;
     // distance of the centre from the solid cone >= p cos - s sin (equality beside the cone's flank; behind the apex the true distance
     // is |v|, which is larger): outside only if that exceeds the radius.  A false comparison (NaN) keeps the primitive.
-    return !(__builtin_fmaf(p, c.cs, -(s * c.sn)) > rr);
+    // ... and the rays leave the fan's plane by at most asin(so): a centre farther from the plane than the radius + |v| so is out of
+    // every ray's reach (a point of a ray at distance t from the apex is within t so of the plane, and t <= |v| + r where it can touch)
+    const float off = fabsf(__builtin_fmaf(v.z, c.nrm.z, __builtin_fmaf(v.y, c.nrm.y, v.x * c.nrm.x)));
+    const float reach = __builtin_fmaf(c.so, __builtin_sqrtf(n2) + r, rr);
+    return !(__builtin_fmaf(p, c.cs, -(s * c.sn)) > rr) && !(off > reach);
 }
-constexpr int kFanMaxPrims = 2048;       // beyond this many primitives the pass over all bounds costs more than the walks it replaces
+
 
 __host__ __device__ inline uint32_t p_cursor_offset(int G, int M) { return q_lds_offset(G, M); }
 __host__ __device__ inline uint32_t p_queue_offset(int G, int M) { return p_cursor_offset(G, M); }

@@ -59,3 +59,32 @@ def test_more_than_256_primitives_with_direct_light_and_flat_mode(pt):
     trf.set_image(None); trf.render(1, 1)
     assert np.array_equal(trf.image(), flat)
     trf.close()
+
+
+@pytest.mark.parametrize("extra,w,h,kw", [(250, 1920, 12, dict()), (250, 1920, 12, dict(antialias=1)), (250, 1280, 10, dict(camera_mode=1)),
+                                          (594, 1920, 8, dict()), (250, 1920, 12, dict(camera_mode=1, aperture=0.2, focal_distance=11.0)),
+                                          (250, 1000, 10, dict(streams=2))])
+def test_camera_groups_on_wide_frames_match_the_oracle(pt, extra, w, h, kw):
+    """k_path_w gives a group of 64 camera rays ONE cone test per primitive instead of 64 grid walks when the group spans a few
+    degrees -- frames a thousand pixels wide and more.  Thin strips of such frames (1 920 / 1 280 / 1 000 pixels: groups that
+    wrap around a row end included) against the oracle: reference camera, jitter, corrected pinhole, thin lens (no cone: walks)."""
+    if extra == 250:
+        sc = orc.load_golden_scene("random256").with_resolution(w, h)
+    else:
+        sc = orc.many_primitives_scene(extra, w=w, h=h)
+    depth, iters = 5, 3
+    okw = {k: v for k, v in kw.items() if k != "streams"}
+    tr = make_tracer(sc, depth=depth, ordering=2, **kw)
+    tr.set_image(None)
+    tr.render(1, iters)
+    want, live = orc.render(sc, oracle_config(depth, **okw), 1, iters)
+    st = tr.stats()
+    assert [st.live[k] for k in range(depth + 1)] == [int(v) for v in live], (extra, w, kw)
+    assert np.array_equal(tr.image(), want), (extra, w, kw)
+    if kw.get("streams", 1) == 1:
+        n, arrs, pix = tr.trace_pool(2, 1)
+        on, oarrs, opix = orc.trace_pool(sc, oracle_config(depth, **okw), 2, 1)
+        order = np.argsort(pix, kind="stable")
+        pix, arrs = pix[order], [x[order] for x in arrs]
+        assert n == on and np.array_equal(pix, opix) and all(np.array_equal(a, b) for a, b in zip(arrs, oarrs)), (extra, w, kw)
+    tr.close()

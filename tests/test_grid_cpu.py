@@ -206,3 +206,56 @@ def test_wide_grid_lists_every_primitive_a_ray_meets_exactly_once(pt, extra, den
         assert not missing.any(), (name, extra, density, np.argwhere(missing)[:5], info)
         total += int(need.sum())
     assert total > 5000
+
+
+@pytest.mark.parametrize("scene,kw", [("random256", dict()), ("random256", dict(antialias=1)), ("random256", dict(camera_mode=1)), ("many1494", dict()),
+                                      ("random256_x1000", dict()), ("random256_x0.05", dict(antialias=1))])
+def test_camera_fan_cone_covers_every_primitive_its_rays_meet(pt, scene, kw):
+    """k_path_w's camera groups: the cone of a group of 64 camera rays (the kernel's own fan_* functions, run on the host by
+    pt_debug_fan_probe) meets every primitive whose geometry any of its rays can meet -- reference camera rays incl. the
+    normalize(R) quirk, jittered ones, the corrected pinhole, scaled scenes; 1920 x 1080 (a group spans 2.6 degrees), a sample of
+    the frame's 32 400 groups."""
+    if scene == "many1494":
+        sc = orc.many_primitives_scene(1494, w=1920, h=1080)
+    elif scene.startswith("random256_x"):
+        sc = _scaled("random256", float(scene.split("x")[1])).with_resolution(1920, 1080)
+    else:
+        sc = orc.load_golden_scene("random256")
+    geoms, _, _ = to_product(sc)
+    lo, hi, ids = _boxes(sc.geoms)
+    n, arrs, pix = orc.trace_pool(sc, orc.default_config(4, **kw), 3, 0)                  # the pool before any bounce: the camera rays
+    assert n == sc.W * sc.H and np.array_equal(pix & 0xFFFFFF, np.arange(n))
+    pick = np.random.default_rng(len(scene)).choice(n // 64, 240, replace=False)
+    rays = np.stack(arrs[:6], 1).reshape(-1, 64, 6)[pick]
+    sets, cones = pt.fan_probe(geoms, rays)
+    assert cones == len(rays)                                                             # 1920 = 30 x 64: no group wraps; every one gets its cone
+    need = _meets(rays.reshape(-1, 6).astype(np.float64), lo, hi)
+    # a sphere is met only where the ray comes within its (largest) radius of the centre -- its box has corners the sphere lacks
+    flat = rays.reshape(-1, 6).astype(np.float64)
+    sph = [col for col, i in enumerate(ids) if sc.geoms[i].type == 0]
+    mats = np.array([[sc.geoms[ids[col]].transform[k] for k in range(12)] for col in sph], dtype=np.float64).reshape(-1, 3, 4)
+    ctr, rad = mats[:, :, 3], 0.5 * np.linalg.norm(mats[:, :, :3], ord=2, axis=(1, 2))
+    for lo_, hi_ in [(k, min(k + 4096, len(flat))) for k in range(0, len(flat), 4096)]:
+        o_, d_ = flat[lo_:hi_, None, :3], flat[lo_:hi_, None, 3:]
+        oc = ctr[None] - o_
+        t = np.maximum((oc * d_).sum(2) / (d_ ** 2).sum(2), 0.0)
+        need[lo_:hi_, sph] &= np.linalg.norm(oc - t[..., None] * d_, axis=2) <= rad[None] * (1 + 1e-9)
+    need = need.reshape(len(rays), 64, -1).any(1)
+    missing = need & ~sets[:, ids]
+    assert not missing.any(), (scene, kw, np.argwhere(missing)[:5])
+    assert sets[:, ids].sum(1).mean() < 40                                                # and it is worth having: a few dozen bounds per group, walls included
+
+
+def test_camera_fan_refuses_what_it_cannot_bound(pt):
+    """no common origin (thin lens), a fan too wide to be worth a cone, non-finite directions: no cone, every bit set (the kernel walks)"""
+    sc = orc.load_golden_scene("random256").with_resolution(128, 64)
+    geoms, _, _ = to_product(sc)
+    n, arrs, pix = orc.trace_pool(sc, orc.default_config(4, camera_mode=1, aperture=0.3, focal_distance=10.0), 1, 0)
+    lens = np.stack(arrs[:6], 1).reshape(-1, 64, 6)[:4]
+    n, arrs, pix = orc.trace_pool(sc, orc.default_config(4), 1, 0)
+    ok = np.stack(arrs[:6], 1).reshape(-1, 64, 6)
+    wrap = np.concatenate([ok[1][32:], ok[2][:32]])[None]                                  # (128 pixels = two groups per row) half a row's end, half the next row's start
+    bad = ok[:1].copy(); bad[0, 5, 3] = np.nan
+    for fans in (lens, wrap, bad):
+        sets, cones = pt.fan_probe(geoms, fans)
+        assert cones == 0 and sets[:, :len(geoms)].all()
