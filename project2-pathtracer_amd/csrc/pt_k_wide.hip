@@ -61,6 +61,9 @@ __device__ __forceinline__ void wstat(int i, unsigned long long v) { if ((thread
 #define PT_WSTAT(i, v) do { } while (0)
 #endif
 
+#ifndef PT_WALK_FLAT
+#define PT_WALK_FLAT 1                  // the walk reads and steps on every lane, walking or not (two exec-masked regions less per trip: 0.8907 -> 0.8847 ms/step)
+#endif
 #ifndef PT_FAN
 #define PT_FAN 1                        // camera groups take one cone test per primitive instead of 64 grid walks (A/B switch; results identical)
 #endif
@@ -461,14 +464,25 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
                         if (wb == 0ull || trips >= max_trips) { walk_left = false; break; }
                         trips++;
                         PT_WSTAT(2, 1); PT_WSTAT(3, __popcll(wb));
+#if PT_WALK_FLAT
+                        // every lane reads and steps, walking or not: a lane that has left the grid holds a meaningless cell index, and an LDS
+                        // read beyond the block's allocation returns zero -- its `emit` is masked below
+                        uint32_t rec = BIG ? ld_cell(gw.walking ? grid_walk_cell(gw) : 0u) : cells[grid_walk_cell(gw)];
+                        const bool emit = gw.walking && (BIG ? rec != 0xFFFFFFFFu : (rec >> 16) != 0u);
+#else
                         uint32_t rec = BIG ? 0xFFFFFFFFu : 0u;
                         if (gw.walking) rec = ld_cell(grid_walk_cell(gw));
                         const bool emit = BIG ? rec != 0xFFFFFFFFu : (rec >> 16) != 0u;
+#endif
                         const u64 eb = __ballot(emit);
                         if (emit) bufA[nA + wave_rank(eb)] = sid | ((BIG ? rec : (rec & 0xFFFFu)) << Fm::kRefShift) | (gw.emask << Fm::kEmaskShift);  // the cell's first reference
                         nA += (uint32_t)__popcll(eb);
                         PT_WSTAT(4, __popcll(eb));
+#if PT_WALK_FLAT
+                        grid_walk_step(gw);
+#else
                         if (gw.walking) grid_walk_step(gw);
+#endif
                         if (nA >= 64u) break;
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
