@@ -51,11 +51,12 @@ WORKLOAD_OPTIONS = {"c5": dict(camera_mode=1, antialias=1, aperture=0.25, focal_
 WORKLOAD_RESOLUTION = {"mesh": "1920x1080", "mesh5k": "1920x1080"}       # these scene files carry a small preview RES
 
 
-def reduce_to_root(tensor, dst=0):
+def reduce_to_root(tensor, dst=0, force=False):
     """Sum the per-rank accumulators on rank `dst` (RCCL over xGMI when backend is nccl).
-    Adding zeros is exact, so the row-sharded sum is bit-identical to a single-GPU render."""
+    Adding zeros is exact, so the row-sharded sum is bit-identical to a single-GPU render.
+    `force`: also with a world of one rank (tests: the RCCL path on the one GPU a test box has)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force):
         dist.reduce(tensor, dst=dst, op=dist.ReduceOp.SUM)
     return tensor
 
@@ -72,10 +73,11 @@ class RowGather:
     strided copy into the frame (a permuted view [world, rows, W*3] of the accumulator when world divides H,
     else one copy per peer)."""
 
-    def __init__(self, like, H, W, dst=0):
+    def __init__(self, like, H, W, dst=0, force=False):
         import torch
         import torch.distributed as dist
-        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        # (`force`: also with a world of one rank -- tests run the RCCL path on the one GPU a test box has)
+        self.active = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force)
         if not self.active:
             return
         self.world, self.rank, self.dst, self.H, self.W = dist.get_world_size(), dist.get_rank(), dst, H, W
@@ -217,13 +219,10 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events in the timed region")
     ap.add_argument("--chunk-rays", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
-    ap.add_argument("--ordering", type=int, default=None, help="0 = stable compaction (library default), 1 = typed work queues, one launch per bounce (<= 32 primitives), "
-                                                             "2 = whole paths, one launch per group: k_path_q (<= 32 primitives) / k_path_w (33..256 analytic primitives). "
+    ap.add_argument("--ordering", type=int, default=None, help="0 = stable compaction, one launch per bounce, 1 = typed work queues, one launch per bounce (<= 32 primitives), "
+                                                             "2 = whole paths, one launch per group (the library default): k_path_q (<= 32 primitives) / k_path_w (more than 32 analytic primitives). "
                                                              "Default: 2; with --direct-light 0 (the per-bounce kernels resolve a shadow ray inline and are the faster form there)")
-    ap.add_argument("--wide-variant", type=int, default=0, help="k_path_w block shape (A/B switch, results identical)")
-    ap.add_argument("--cluster-size", type=int, default=0, help="members per spatial cluster for scenes of 33..256 primitives (0 = default)")
     ap.add_argument("--grid-density", type=int, default=0, help="k_path_w: cells of its uniform grid per small primitive (0 = default 4)")
-    ap.add_argument("--static-eighths", type=int, default=4, help="whole-path kernels: eighths of the camera-ray jobs owned statically by the waves")
     ap.add_argument("--batch", type=int, default=0, help="iterations per launch group (0 = auto, 1 = off)")
     ap.add_argument("--resolution", default="", help="WxH override of the scene RES line (experiments only)")
     ap.add_argument("--culling", type=int, default=0, help="0 = AABB candidate culling (default), 1 = brute force")
@@ -314,8 +313,7 @@ def main():
     accum = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda:%d" % device)
     tracer = pkg.PathTracer(pkg.default_config(device=device, max_depth=depth, row_offset=rank, row_stride=world, streams=S,
                                                chunk_rays=args.chunk_rays, blocks_per_cu=args.blocks_per_cu, culling=args.culling, batch=args.batch,
-                                               ordering=args.ordering, direct_light=args.direct_light, wide_variant=args.wide_variant,
-                                               cluster_size=args.cluster_size, grid_density=args.grid_density, path_static_eighths=args.static_eighths, **options))
+                                               ordering=args.ordering, direct_light=args.direct_light, grid_density=args.grid_density, **options))
     meshes = sf.meshes()
     if meshes:
         tracer.set_meshes(meshes)

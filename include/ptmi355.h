@@ -35,8 +35,11 @@ extern "C" {
  * 7: geometry_path, compaction = 1 (look-back scan) and merge_floor are gone (measured slower; the fields stay and
  *    must be 0); reserved[3] became cluster_size / path_static_eighths / wide_variant (they replace environment
  *    switches the library used to read); ordering = 2 also covers scenes of 33..256 analytic primitives (k_path_w)
- * 8: + pt_config.grid_density (k_path_w walks a uniform grid over the small primitives instead of testing every cluster box) */
-#define PTMI355_ABI_VERSION 8
+ * 8: + pt_config.grid_density (k_path_w walks a uniform grid over the small primitives instead of testing every cluster box)
+ * 9: pt_config loses the fields that had to be 0 (geometry_path, compaction, merge_floor, bvh) and the A/B switches whose best
+ *    setting is built in (cluster_size, path_static_eighths, wide_variant): 18 fields; pt_config_default now gives the fast path
+ *    (ordering = 2, streams = 2); ordering = 2 takes any number of analytic primitives; + pt_debug_fan_probe */
+#define PTMI355_ABI_VERSION 9
 
 typedef enum {
     PT_OK = 0,
@@ -84,7 +87,9 @@ typedef struct {
 } pt_camera;
 
 /* Render options the reference hard-codes or lacks (traceDepth src/raytraceKernel.cu:166;
- * README.md:47-51,63).  Zero-initialise, then pt_config_default(). */
+ * README.md:47-51,63).  Always fill through pt_config_default() first, then change what differs: fields added later keep their
+ * defaults.  pt_config_default gives the fast path: whole paths in one launch per group of iterations (ordering = 2) on two
+ * streams per GPU (streams = 2), 8 bounces, all rows. */
 typedef struct {
     int   device;            /* HIP device ordinal */
     int   mode;              /* 0 = path trace (generate -> bounce* -> accumulate)
@@ -98,50 +103,37 @@ typedef struct {
     float focal_distance;
     int   row_offset;        /* multi-GPU: this context owns rows y with y % row_stride == */
     int   row_stride;        /*   row_offset (single GPU: 0, 1) */
-    int   geometry_path;     /* removed in ABI 7, must be 0: the geometry table lives in LDS whenever it fits (about
-                                1 100 primitives); larger scenes use scalar loads automatically */
     int   chunk_rays;        /* slots per pool segment (0 = by launch size) / camera rays per job of the whole-path kernels */
     int   blocks_per_cu;     /* persistent grid size = CUs * this (0 = default) */
     int   profile;           /* 1 = bracket every kernel launch with HIP events */
-    int   compaction;        /* removed in ABI 7, must be 0: wave-autonomous segmented compaction (ballot + mbcnt ranks
-                                inside a wave, one wave per pool segment) is the only form */
-    int   culling;           /* 0 = conservative AABB candidate culling before the exact tests (default;
-                                results identical), 1 = brute force over all primitives */
-    int   merge_floor;       /* removed in ABI 7, must be 0 */
-    int   batch;             /* iterations that may share one launch group in pt_render (0 = auto: about
-                                32 M rays per launch, at most 128; 1 = one iteration per launch).  Results
-                                are identical: each in-flight iteration accumulates into its own plane
-                                and the planes are folded into the image in iteration order. */
-    int   ordering;          /* 0 = stable: the compacted stream keeps generation order (default)
-                                1 = typed work queues (<= 32 primitives, LDS tables): the unit of work is one exact
-                                    test of a ray against its nearest candidate; rays wait on wave-private LDS stacks
-                                    by candidate type and both stages run on full waves; survivors fill the wave's own
-                                    segments densely (fastest; survivors keep their wave, not their segment or order;
-                                    results identical).
-                                2 = whole paths on the typed work queues: ONE launch per group; waves draw jobs of camera
-                                    rays from a ticket counter and keep every ray from the camera to its end (queue records
-                                    carry the ray and its bounce level, survivors wait on small per-wave stacks);
-                                    <= 32 primitives: k_path_q; 33..256 analytic primitives: k_path_w (rays walk a uniform grid;
-                                    dense (ray, cell) and (ray, primitive) pairs, type-pure exact tests on full waves); results
-                                    identical.  Other values behave like 0. */
-    int   bvh;               /* unused (round-1 experiments, removed); scenes with 33..256 analytic primitives use
-                                two-level cluster culling automatically, meshes carry their own BVH */
+    int   culling;           /* 0 = conservative candidate culling before the exact tests (default; results identical),
+                                1 = brute force over all primitives (per-bounce kernels) */
+    int   batch;             /* iterations that may share one launch group in pt_render (1 = one iteration per launch; 0 = auto:
+                                about 96 M rays per launch for the whole-path kernels, 32 M for the per-bounce kernels, whose two
+                                ray pools grow with it; at most 128 iterations).  Results are identical: each in-flight iteration
+                                accumulates into its own plane of the owned pixels (12 bytes each: up to 1.15 GB per stream at
+                                1080p with the auto group, never more than 4 GiB) and the planes are folded into the image in
+                                iteration order. */
+    int   ordering;          /* which kernel family renders; results are identical.
+                                2 = whole paths, ONE launch per group of iterations (pt_config_default): waves draw jobs of camera
+                                    rays and keep every ray from the camera to its end; up to 32 primitives on typed work queues
+                                    (k_path_q, also with registered meshes or direct_light), more than 32 analytic primitives --
+                                    any number -- on a uniform grid with dense (ray, cell) and (ray, primitive) pairs (k_path_w:
+                                    byte ids and the geometry table in LDS up to 256 primitives, wide ids and gathers from global
+                                    memory beyond).
+                                1 = typed work queues, one launch per bounce (<= 32 primitives).
+                                0 = stable: one launch per bounce, the compacted ray stream keeps generation order -- what the
+                                    parity hooks (pt_debug_trace_pool, pt_debug_primary_hits) compare against.
+                                Scenes a family does not take fall back to the next one down.  Other values behave like 0. */
     int   direct_light;      /* 1 = next-event estimation: at every diffuse hit one shadow
                                 ray to a point drawn by getRandomPointOnCube / getRandomPointOnSphere
                                 (src/intersections.h:220-286) on a random emitter; emitter hits then add
                                 radiance only for camera rays and after specular events.  Same expectation
-                                as mode 0 without it, far less noise for small lights.  Needs compaction=0,
-                                culling=0, geometry_path=0 (LDS tables); ordering is ignored. */
-    int   streams;           /* 1 = one HIP stream (default).  n > 1: the context shards its rows once more over n
-                                internal contexts, each on its own stream, all rendering into the same image and
-                                all enqueued before any is awaited: the tails of one stream's launches are filled
-                                by the others' (mode 0; bit-identical; parity hooks need 1).  DESIGN.md section 4. */
-    int   cluster_size;      /* scenes of 33..256 primitives: preferred members per spatial cluster of the two-level
-                                culling (0 = default; the library grows it until the clusters fit their mask) */
-    int   path_static_eighths; /* whole-path kernels: share of the camera-ray jobs every wave owns statically, in
-                                eighths (pt_config_default: 4 = half); the rest is drawn from ticket counters */
-    int   wide_variant;      /* k_path_w block shape: 0 = default, 1..2 = other waves-per-block / ray-slot splits of
-                                the CU's LDS (A/B switch; results identical) */
+                                as mode 0 without it, far less noise for small lights.  Needs culling = 0. */
+    int   streams;           /* n > 1 (pt_config_default: 2): the context shards its rows once more over n internal contexts,
+                                each on its own stream, all rendering into the same image and all enqueued before any is
+                                awaited: the tails of one stream's launches are filled by the others' (mode 0; bit-identical).
+                                1 = one HIP stream; the parity hooks need 1.  DESIGN.md section 4. */
     int   grid_density;      /* k_path_w: cells of its uniform grid per small primitive (0 = default 4; 1..64).  The grid only
                                 decides which bounds a ray tests; results identical. */
 } pt_config;

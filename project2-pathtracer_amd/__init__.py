@@ -42,13 +42,13 @@ class Camera(C.Structure):     # == pt_camera == reference `cameraData` (sceneSt
                 ("up", C.c_float * 3), ("fov", C.c_float * 2)]
 
 
-class Config(C.Structure):     # == pt_config
+class Config(C.Structure):     # == pt_config (ABI 9)
     _fields_ = [("device", C.c_int), ("mode", C.c_int), ("max_depth", C.c_int), ("camera_mode", C.c_int),
                 ("antialias", C.c_int), ("aperture", C.c_float), ("focal_distance", C.c_float),
-                ("row_offset", C.c_int), ("row_stride", C.c_int), ("geometry_path", C.c_int),
+                ("row_offset", C.c_int), ("row_stride", C.c_int),
                 ("chunk_rays", C.c_int), ("blocks_per_cu", C.c_int), ("profile", C.c_int),
-                ("compaction", C.c_int), ("culling", C.c_int), ("merge_floor", C.c_int), ("batch", C.c_int), ("ordering", C.c_int), ("bvh", C.c_int), ("direct_light", C.c_int), ("streams", C.c_int),
-                ("cluster_size", C.c_int), ("path_static_eighths", C.c_int), ("wide_variant", C.c_int), ("grid_density", C.c_int)]
+                ("culling", C.c_int), ("batch", C.c_int), ("ordering", C.c_int), ("direct_light", C.c_int), ("streams", C.c_int),
+                ("grid_density", C.c_int)]
 
 
 class Mesh(C.Structure):       # == pt_mesh

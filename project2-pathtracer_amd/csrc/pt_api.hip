@@ -47,7 +47,7 @@ struct pt_context {
     uint32_t *d_tickets = nullptr;   //   [kTicketCtrs][kTicketStride]
     size_t arena_bytes = 0;
     int grid_path = 0;
-    uint32_t path_static_eighths = 4;
+    uint32_t path_static_eighths = 4; //   eighths of the camera-ray jobs every wave owns statically (half: all-static 9 % slower, all-drawn 2 %)
     uint32_t path_waves = 4;         //   waves per block of the whole-path kernel in use
     int wide_shape = 0;              //   k_path_w: block shape (0 / 1 narrow ids, 2 / 3 wide ids: pt_k_wide.hip)
     bool wide_big = false;           //   more than 256 primitives: wide ids, geometry gathered from global memory
@@ -263,7 +263,7 @@ int enqueue_iterations(pt_context *c, uint32_t iteration, uint32_t batch, int st
             if (job > kJobMax) job = kJobMax;
             if (c->cfg.chunk_rays > 0) job = (uint32_t)((c->cfg.chunk_rays + 63) & ~63);      // explicit
             pa.job_rays = job;
-            // static share of the jobs: cfg.path_static_eighths / 8 (default: half)
+            // static share of the jobs: half
             const uint64_t njobs = ((uint64_t)n_rays + job - 1) / job;
             pa.static_rounds = (uint32_t)(njobs * c->path_static_eighths / 8u / waves);
         }
@@ -354,13 +354,9 @@ int pt_create(const pt_config *cfg, pt_context **out) {
     // argument checks need no device
     if (cfg->max_depth < 1 || cfg->max_depth > 64) { pth::set_error("pt_create: max_depth %d not in 1..64", cfg->max_depth); return PT_ERR_ARGUMENT; }
     if (cfg->row_stride < 1 || cfg->row_offset < 0 || cfg->row_offset >= cfg->row_stride) { pth::set_error("pt_create: bad row_offset/row_stride"); return PT_ERR_ARGUMENT; }
-    if (cfg->geometry_path != 0 || cfg->compaction != 0 || cfg->merge_floor != 0) {
-        pth::set_error("pt_create: geometry_path / compaction / merge_floor were removed in ABI 7 (measured slower than the defaults); leave them 0");
-        return PT_ERR_ARGUMENT;
-    }
-    if (cfg->path_static_eighths < 0 || cfg->path_static_eighths > 8) { pth::set_error("pt_create: path_static_eighths %d not in 0..8", cfg->path_static_eighths); return PT_ERR_ARGUMENT; }
-    if (cfg->cluster_size < 0 || cfg->cluster_size > 16) { pth::set_error("pt_create: cluster_size %d not in 0..16", cfg->cluster_size); return PT_ERR_ARGUMENT; }
     if (cfg->grid_density < 0 || cfg->grid_density > 64) { pth::set_error("pt_create: grid_density %d not in 0..64", cfg->grid_density); return PT_ERR_ARGUMENT; }
+    if (cfg->streams < 1 || cfg->streams > 8) { pth::set_error("pt_create: streams %d not in 1..8", cfg->streams); return PT_ERR_ARGUMENT; }
+    if (cfg->batch < 0 || cfg->chunk_rays < 0 || cfg->blocks_per_cu < 0) { pth::set_error("pt_create: batch / chunk_rays / blocks_per_cu must not be negative"); return PT_ERR_ARGUMENT; }
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
         pth::set_error("pt_create: no HIP device visible (this library has no CPU fallback)");
@@ -375,7 +371,6 @@ int pt_create(const pt_config *cfg, pt_context **out) {
         return PT_ERR_NO_DEVICE;
     }
     if (cfg->streams > 1 && cfg->mode == 0) {
-        if (cfg->streams > 8) { pth::set_error("pt_create: streams %d not in 1..8", cfg->streams); return PT_ERR_ARGUMENT; }
         pt_context *parent = new pt_context();
         parent->cfg = *cfg;
         if (hipStreamCreateWithFlags(&parent->stream, hipStreamNonBlocking) != hipSuccess) { delete parent; pth::set_error("hipStreamCreate failed"); return PT_ERR_HIP; }
@@ -784,7 +779,6 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
         HIPCHK(hipMalloc(&c->d_frames, fr.size() * sizeof(FaceFrame)));
         HIPCHK(hipMemcpy(c->d_frames, fr.data(), fr.size() * sizeof(FaceFrame), hipMemcpyHostToDevice));
     }
-    c->path_static_eighths = (uint32_t)c->cfg.path_static_eighths;
     pth::camera_basis(cam, &c->cfg, &c->cam);
     c->scene_ready = true;
     return PT_OK;

@@ -745,10 +745,10 @@ __host__ __device__ __forceinline__ GridWalk grid_walk_begin(const GridArgs &ga,
     w.walking = wanted && !(t0m > t1p);
     const f3 ps = mk(__builtin_fmaf(d.x, t0, o.x), __builtin_fmaf(d.y, t0, o.y), __builtin_fmaf(d.z, t0, o.z));
     const bool ngx = inv.x < 0.0f, ngy = inv.y < 0.0f, ngz = inv.z < 0.0f;
-    int ix = (int)floorf((ps.x - gx0) * ga.inv_h[0]), iy = (int)floorf((ps.y - gy0) * ga.inv_h[1]), iz = (int)floorf((ps.z - gz0) * ga.inv_h[2]);
-    ix = ix < 0 ? 0 : (ix > nx - 1 ? nx - 1 : ix);
-    iy = iy < 0 ? 0 : (iy > ny - 1 ? ny - 1 : iy);
-    iz = iz < 0 ? 0 : (iz > nz - 1 ? nz - 1 : iz);
+    // (clamped as floats: a degenerate ray's entry point may be far outside what an int holds; NaN -> 0)
+    const int ix = (int)fminf(fmaxf(floorf((ps.x - gx0) * ga.inv_h[0]), 0.0f), (float)(nx - 1));
+    const int iy = (int)fminf(fmaxf(floorf((ps.y - gy0) * ga.inv_h[1]), 0.0f), (float)(ny - 1));
+    const int iz = (int)fminf(fmaxf(floorf((ps.z - gz0) * ga.inv_h[2]), 0.0f), (float)(nz - 1));
     w.c0 = (float)(ix + nx * (iy + ny * iz));
     w.scx = ngx ? -1.0f : 1.0f; w.scy = (float)(ngy ? -nx : nx); w.scz = (float)(ngz ? -(nx * ny) : nx * ny);
     w.kmx = (float)(ngx ? ix : nx - 1 - ix); w.kmy = (float)(ngy ? iy : ny - 1 - iy); w.kmz = (float)(ngz ? iz : nz - 1 - iz);

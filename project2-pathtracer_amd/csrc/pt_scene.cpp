@@ -290,8 +290,8 @@ void pt_config_default(pt_config *cfg) {
     memset(cfg, 0, sizeof *cfg);
     cfg->max_depth = 8;
     cfg->row_stride = 1;
-    cfg->streams = 1;
-    cfg->path_static_eighths = 4;
+    cfg->ordering = 2;           // whole paths, one launch per group of iterations
+    cfg->streams = 2;            // two streams per GPU: one's launch tails are filled by the other's blocks
 }
 
 int pt_build_transform(const float t[3], const float r[3], const float s[3], float xf[16], float inv[16]) {

@@ -25,7 +25,12 @@ def to_product(scene):
 
 
 def make_tracer(scene, depth=8, **kw):
+    """A context for the parity tests.  Unless a test says otherwise it is the STABLE kernel family on one stream (ordering = 0,
+    streams = 1): what the parity hooks compare against -- pt_config_default itself gives the fast path (ordering = 2, two streams),
+    which the tests ask for by name."""
     pkg = load_package()
+    kw.setdefault("ordering", 0)
+    kw.setdefault("streams", 1)
     cfg = pkg.default_config(max_depth=depth, **kw)
     tr = pkg.PathTracer(cfg)
     if getattr(scene, "meshes", None):

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(pkg):
         assert hasattr(L, name), "libptmi355.so does not export %s" % name
     assert sorted(pkg.EXPORTS) == declared
     version = int(re.search(r"#define\s+PTMI355_ABI_VERSION\s+(\d+)", hdr).group(1))
-    assert pkg.lib().pt_abi_version() == version == 8
+    assert pkg.lib().pt_abi_version() == version == 9
 
 
 def test_pod_sizes_match_reference_structs(pkg):
@@ -50,16 +50,25 @@ def test_no_cpu_fallback(pkg):
     assert pkg.lib().pt_render(None, 1, 1) != 0
 
 
-def test_options_retired_in_abi7_are_refused_before_any_device_is_touched(pkg):
-    """geometry_path=1, the look-back scan (compaction=1) and merge_floor were measured losers and left the launch
-    matrix in ABI 7: the fields stay (layout), non-zero values are an argument error -- with or without a GPU."""
+def test_bad_options_are_refused_before_any_device_is_touched_and_the_default_is_the_fast_path(pkg):
+    """Out-of-range options are an argument error -- with or without a GPU.  ABI 9: the fields that had to be zero and the A/B
+    switches whose best setting is built in are gone (18 fields), and pt_config_default gives what bench.py, the adaptor
+    and ptrender run: whole paths in one launch per group (ordering = 2) on two streams per GPU."""
     import ctypes as C
-    for kw in (dict(geometry_path=1), dict(compaction=1), dict(merge_floor=4), dict(path_static_eighths=9), dict(cluster_size=99), dict(grid_density=65), dict(grid_density=-1)):
+    for kw in (dict(grid_density=65), dict(grid_density=-1), dict(max_depth=0), dict(max_depth=65), dict(row_stride=0), dict(streams=0)):
         cfg = pkg.default_config(**kw)
         h = C.c_void_p()
         assert pkg.lib().pt_create(C.byref(cfg), C.byref(h)) == -3, kw          # PT_ERR_ARGUMENT
         assert not h.value
-    assert pkg.default_config().path_static_eighths == 4 and pkg.default_config().grid_density == 0       # (ABI 8: 0 = four cells per small primitive)
+    d = pkg.default_config()
+    assert (d.ordering, d.streams, d.max_depth, d.row_stride, d.grid_density, d.batch) == (2, 2, 8, 1, 0, 0)
+    assert C.sizeof(pkg.Config) == 18 * 4
+    for gone in ("geometry_path", "compaction", "merge_floor", "bvh", "cluster_size", "path_static_eighths", "wide_variant"):
+        assert not hasattr(d, gone)
+    header = open(os.path.join(ROOT, "include", "ptmi355.h")).read()
+    body = header[header.index("typedef struct {\n    int   device;"):header.index("} pt_config;")]
+    fields = re.findall(r"^    (?:int|float)\s+(\w+);", body, re.M)
+    assert fields == [f for f, _ in pkg.Config._fields_], fields              # the ctypes mirror follows the header, field for field
 
 
 def test_library_reads_no_environment_switches():

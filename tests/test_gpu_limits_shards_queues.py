@@ -226,7 +226,7 @@ def _stacked_scene(w, h):
 
 
 @pytest.mark.parametrize("kw", [dict(ordering=0), dict(ordering=1), dict(ordering=1, streams=2, batch=2), dict(ordering=2), dict(ordering=2, streams=2, batch=2),
-                                dict(ordering=2, wide_variant=2, cluster_size=3)])
+                                dict(ordering=2, grid_density=2, chunk_rays=64)])
 def test_many_primitive_kernels_when_the_candidate_list_overflows(pt, kw):
     """The many-primitive kernels keep at most 8 candidates per ray in registers; a ray with more takes the reference's
     brute-force loop.  Here nearly every ray does."""
@@ -258,20 +258,21 @@ def test_fold_of_batched_iterations_at_odd_widths(pt, w, h):
         tr.close()
 
 
-@pytest.mark.parametrize("eighths", [0, 8, 3])
-def test_whole_path_kernel_job_hand_out_all_drawn_all_static_and_mixed(pt, eighths):
-    """ordering = 2: the jobs of camera rays are partly the waves' own contiguous ranges, partly drawn from sixteen ticket
-    counters (pt_config.path_static_eighths).  Whatever the split -- all drawn, all static but the remainder, mixed --
-    every camera ray is rendered exactly once: image and live counts are the oracle's."""
+@pytest.mark.parametrize("job", [0, 64, 128, 1024])
+def test_whole_path_kernel_job_hand_out_whatever_the_job_size(pt, job):
+    """ordering = 2: the jobs of camera rays are half the waves' own contiguous ranges, half drawn from sixteen ticket
+    counters.  Whatever the job size (pt_config.chunk_rays; 0 = by launch size), the launch-group size and the grid --
+    jobs that do not divide the frame, more waves than jobs, one block per CU -- every camera ray is rendered exactly
+    once: image and live counts are the oracle's."""
     sc = orc.load_golden_scene("cornell_mirror").with_resolution(213, 117)
-    for kw in (dict(ordering=2, batch=4), dict(ordering=2, streams=2, batch=3, chunk_rays=64), dict(ordering=2, batch=1, blocks_per_cu=1)):
-        tr = make_tracer(sc, depth=6, path_static_eighths=eighths, **kw)
+    for kw in (dict(ordering=2, batch=4), dict(ordering=2, streams=2, batch=3), dict(ordering=2, batch=1, blocks_per_cu=1)):
+        tr = make_tracer(sc, depth=6, chunk_rays=job, **kw)
         tr.set_image(None)
         tr.render(1, 7)
         want, live = orc.render(sc, oracle_config(6), 1, 7)
         st = tr.stats()
-        assert [st.live[k] for k in range(7)] == [int(v) for v in live], (eighths, kw)
-        assert np.array_equal(tr.image(), want), (eighths, kw)
+        assert [st.live[k] for k in range(7)] == [int(v) for v in live], (job, kw)
+        assert np.array_equal(tr.image(), want), (job, kw)
         tr.close()
 
 

@@ -372,8 +372,8 @@ def test_full_size_properties_1080p(pt):
 
 @pytest.mark.parametrize("kw", [dict(), dict(batch=2, chunk_rays=100), dict(culling=1), dict(streams=2), dict(direct_light=1),
                                 dict(ordering=1), dict(ordering=1, batch=3, chunk_rays=128), dict(ordering=1, streams=2),
-                                dict(ordering=2), dict(ordering=2, batch=3, chunk_rays=128), dict(ordering=2, streams=2), dict(ordering=2, wide_variant=1), dict(ordering=2, wide_variant=2),
-                                dict(ordering=2, cluster_size=4), dict(ordering=2, cluster_size=16), dict(ordering=2, path_static_eighths=0), dict(ordering=2, path_static_eighths=8, batch=1)])
+                                dict(ordering=2), dict(ordering=2, batch=3, chunk_rays=128), dict(ordering=2, streams=2), dict(ordering=2, grid_density=1), dict(ordering=2, grid_density=16),
+                                dict(ordering=2, chunk_rays=64, batch=1), dict(ordering=2, blocks_per_cu=1, batch=2)])
 def test_many_primitives_scene_matches_oracle(pt, kw):
     """BASELINE config 4's scene (256 spheres+cubes incl. rotated cubes, mirrors, glass): the two-level
     candidate culling must never change the nearest hit."""
@@ -442,7 +442,7 @@ def test_config4_and_config5_full_size_slices(pt):
     rows = np.arange(1080) % 270 == 11
     assert np.array_equal(full[rows], want[rows])
     # what bench.py --workload c4 times: the whole-path kernel for 33..256 primitives (k_path_w), two contexts
-    for kwq in (dict(ordering=2, streams=2), dict(ordering=2, wide_variant=1), dict(ordering=1, streams=2)):
+    for kwq in (dict(ordering=2, streams=2), dict(ordering=2, streams=1), dict(ordering=1, streams=2)):
         trq = make_tracer(c4, **kwq)
         trq.set_image(None); trq.render(1, 1)
         stq = trq.stats()

@@ -27,7 +27,7 @@ def _subset(name, keep, w, h):
     ("spheres only, no enclosing room: most rays leave without a candidate", [i for i in range(6, 256) if i % 2 == 0][:90]),
     ("all 256", list(range(256))),
 ])
-@pytest.mark.parametrize("kw", [dict(), dict(wide_variant=1, batch=3), dict(wide_variant=2, streams=2), dict(cluster_size=5, chunk_rays=64)])
+@pytest.mark.parametrize("kw", [dict(), dict(grid_density=2, batch=3), dict(grid_density=12, streams=2), dict(chunk_rays=64)])
 def test_whole_path_wide_kernel_on_subsets_of_config4(pt, label, keep, kw):
     """k_path_w (ordering = 2, 33..256 analytic primitives) against the oracle: image, live counts, emitter hits; and
     against the stable kernel's ray pool of the same context (the parity hook runs the per-bounce WIDE kernel)."""
@@ -59,7 +59,7 @@ def test_whole_path_wide_kernel_continues_a_host_image_and_long_groups(pt):
     tr.close()
 
 
-@pytest.mark.parametrize("name,kw", [("cornell_mirror", dict()), ("random256", dict()), ("random256", dict(wide_variant=2))])
+@pytest.mark.parametrize("name,kw", [("cornell_mirror", dict()), ("random256", dict()), ("random256", dict(grid_density=1))])
 def test_turn_limit_guard_surfaces_through_sync(pt, name, kw):
     """The whole-path kernels bound the scheduling turns of a wave (a broken build must end, not hang the device).  With
     the limit lowered to a few turns the guard trips: the launch ends at once and pt_sync reports PT_ERR_HIP."""
@@ -232,3 +232,18 @@ def test_whole_path_kernel_shape_follows_the_scene(pt):
     assert e["family"] == "k_path_q" and e["direct_light"] and e["blocks_per_cu"] == 5
     assert shape("cornell_mirror", ordering=0)["family"] == "per-bounce"
 
+
+
+def test_exchange_code_runs_under_rccl_with_one_rank(pt, tmp_path):
+    """bench.py's per-frame exchange (RowGather on device tensors, reduce, all-reduce, barrier) under backend "nccl" = RCCL with a
+    world of ONE rank on this box's GPU: communicator creation and the device-tensor path execute, and the gathered frame is the
+    oracle's.  (A child process: the test process keeps no process group.  The multi-GPU curve itself is the driver's to measure.)"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "frame.npy")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_worker.py"), str(port), out], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
+    sc = orc.load_golden_scene("cornell_mirror").with_resolution(96, 55)
+    want, _ = orc.render(sc, oracle_config(6), 1, 3)
+    assert np.array_equal(np.load(out), want)

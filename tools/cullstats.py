@@ -10,7 +10,7 @@ sys.path.insert(0, os.getcwd())
 # select the -DPT_CULL_STATS build with PTMI355_LIB (tools/build_variant.sh stats -DPT_CULL_STATS)
 pkg = importlib.import_module("project2-pathtracer_amd")
 sf = pkg.SceneFile(sys.argv[1] if len(sys.argv) > 1 else "scenes/cornell_mirror.txt"); g, m, cam = sf.flatten(0)
-tr = pkg.PathTracer(pkg.default_config(max_depth=8, batch=1)); tr.upload(g, m, cam); tr.set_image(None)
+tr = pkg.PathTracer(pkg.default_config(streams=1, max_depth=8, batch=1)); tr.upload(g, m, cam); tr.set_image(None)
 tr.render(1, 2); tr.sync()
 out = (C.c_ulonglong * 16)(); pkg.lib().pt_debug_cull_stats(out)
 g0, bi, ba, si, sa, cand = out[0], out[1], out[2], out[3], out[4], out[5]

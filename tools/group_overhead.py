@@ -11,7 +11,7 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 chunk = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 sf = pkg.SceneFile(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenes", "cornell_mirror.txt"))
 g, m, cam = sf.flatten(0)
-tr = pkg.PathTracer(pkg.default_config(max_depth=8, ordering=1, row_offset=0, row_stride=shards, chunk_rays=chunk))
+tr = pkg.PathTracer(pkg.default_config(streams=1, max_depth=8, ordering=1, row_offset=0, row_stride=shards, chunk_rays=chunk))
 tr.upload(g, m, cam); tr.set_image(None)
 tr.render(1, steps); tr.sync()
 t0 = time.perf_counter()

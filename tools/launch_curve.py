@@ -7,7 +7,7 @@ world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 scene = sys.argv[2] if len(sys.argv) > 2 else "scenes/cornell_mirror.txt"
 pipe = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 sf = pkg.SceneFile(scene); g, m, cam = sf.flatten(0)
-tr = pkg.PathTracer(pkg.default_config(max_depth=8, ordering=2, row_offset=0, row_stride=world))
+tr = pkg.PathTracer(pkg.default_config(streams=1, max_depth=8, ordering=2, row_offset=0, row_stride=world))
 tr.upload(g, m, cam); tr.set_image(None)
 tr.render(1, 40); tr.sync()
 rows = []

@@ -7,7 +7,7 @@ pkg = importlib.import_module("project2-pathtracer_amd")
 scene = sys.argv[1] if len(sys.argv) > 1 else "scenes/cornell_mesh.txt"
 sf = pkg.SceneFile(scene); g, m, cam = sf.flatten(0)
 cam.resolution[0], cam.resolution[1] = 1920.0, 1080.0
-tr = pkg.PathTracer(pkg.default_config(max_depth=8, ordering=2)); tr.set_meshes(sf.meshes()); tr.upload(g, m, cam); tr.set_image(None)
+tr = pkg.PathTracer(pkg.default_config(streams=1, max_depth=8, ordering=2)); tr.set_meshes(sf.meshes()); tr.upload(g, m, cam); tr.set_image(None)
 tr.render(1, 20); tr.sync()
 st = tr.stats()
 out = (C.c_ulonglong * 16)(); pkg.lib().pt_debug_cull_stats.argtypes = [C.POINTER(C.c_ulonglong)]; pkg.lib().pt_debug_cull_stats(out)

@@ -8,7 +8,7 @@ pkg = importlib.import_module("project2-pathtracer_amd")
 sf = pkg.SceneFile(sys.argv[1] if len(sys.argv) > 1 else "scenes/cornell_mirror.txt"); g, m, cam = sf.flatten(0)
 depth = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 ordering = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-tr = pkg.PathTracer(pkg.default_config(max_depth=depth, ordering=ordering)); tr.upload(g, m, cam); tr.set_image(None)
+tr = pkg.PathTracer(pkg.default_config(streams=1, max_depth=depth, ordering=ordering)); tr.upload(g, m, cam); tr.set_image(None)
 tr.render(1, 16); tr.sync()
 st = tr.stats()
 live = sum(st.live[k] for k in range(depth))

@@ -20,7 +20,7 @@ def main():
     direct = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     sf = pkg.SceneFile(scene)
     g, m, cam = sf.flatten(0)
-    tr = pkg.PathTracer(pkg.default_config(max_depth=depth, ordering=1, direct_light=direct))
+    tr = pkg.PathTracer(pkg.default_config(streams=1, max_depth=depth, ordering=1, direct_light=direct))
     meshes = sf.meshes()
     if meshes:
         tr.set_meshes(meshes)

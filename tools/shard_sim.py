@@ -22,7 +22,7 @@ base = {}
 for world in WORLDS:
     trs = []
     for r in range(S):                     # rank 0 of `world`: rows y % (world*S) == r*world
-        tr = pkg.PathTracer(pkg.default_config(**dict(dict(max_depth=8, ordering=1, row_offset=r * world, row_stride=world * S), **KW)))
+        tr = pkg.PathTracer(pkg.default_config(**dict(dict(streams=1, max_depth=8, ordering=1, row_offset=r * world, row_stride=world * S), **KW)))
         tr.upload(g, m, cam)
         tr.set_image(None)
         trs.append(tr)

@@ -15,7 +15,7 @@ g, m, cam = sf.flatten(0)
 for n in (1, 2, 3, 4):
     trs = []
     for r in range(n):
-        tr = pkg.PathTracer(pkg.default_config(max_depth=8, ordering=1, row_offset=r, row_stride=n))
+        tr = pkg.PathTracer(pkg.default_config(streams=1, max_depth=8, ordering=1, row_offset=r, row_stride=n))
         tr.upload(g, m, cam)
         tr.set_image(None)
         trs.append(tr)

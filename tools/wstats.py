@@ -7,7 +7,7 @@ pkg = importlib.import_module("project2-pathtracer_amd")
 args = [a for a in sys.argv[1:] if "=" not in a]
 kw = {k: int(v) for k, v in (a.split("=") for a in sys.argv[1:] if "=" in a)}
 sf = pkg.SceneFile(args[0] if args else "scenes/random256.txt"); g, m, cam = sf.flatten(0)
-tr = pkg.PathTracer(pkg.default_config(max_depth=8, ordering=2, **kw)); tr.upload(g, m, cam); tr.set_image(None)
+tr = pkg.PathTracer(pkg.default_config(streams=1, max_depth=8, ordering=2, **kw)); tr.upload(g, m, cam); tr.set_image(None)
 tr.render(1, 4); tr.sync()
 st = tr.stats()
 out = (C.c_ulonglong * 32)(); pkg.lib().pt_debug_wide_stats(out)
