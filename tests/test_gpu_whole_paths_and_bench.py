@@ -59,7 +59,7 @@ def test_whole_path_wide_kernel_continues_a_host_image_and_long_groups(pt):
     tr.close()
 
 
-@pytest.mark.parametrize("name,kw", [("cornell_mirror", dict()), ("random256", dict()), ("random256", dict(grid_density=1))])
+@pytest.mark.parametrize("name,kw", [("cornell_mirror", dict()), ("random256", dict()), ("random256", dict(grid_density=1)), ("cornell_mirror", dict(streams=2))])
 def test_turn_limit_guard_surfaces_through_sync(pt, name, kw):
     """The whole-path kernels bound the scheduling turns of a wave (a broken build must end, not hang the device).  With
     the limit lowered to a few turns the guard trips: the launch ends at once and pt_sync reports PT_ERR_HIP."""
@@ -92,7 +92,7 @@ def test_stack_overflow_guard_surfaces_through_sync(pt):
     L.pt_last_error.restype = C.c_char_p
     sc = orc.load_golden_scene("cornell_mirror").with_resolution(320, 180)
     geoms, mats, cam = to_product(sc)
-    cfg = pt.default_config(max_depth=8, ordering=2)
+    cfg = pt.default_config(max_depth=8, ordering=2, streams=1)        # (one stream: the whole frame's population on every wave)
     h = C.c_void_p()
     assert L.pt_create(C.byref(cfg), C.byref(h)) == 0
     assert L.pt_upload_scene(h, geoms, len(geoms), mats, len(mats), C.byref(cam)) == 0
