@@ -1,18 +1,20 @@
-// pt_k_wide.hip -- `ordering = 2` for scenes of 33..256 analytic primitives: whole paths in ONE launch per group of
-// iterations, with every expensive step on dense, type-pure waves.
+// pt_k_wide.hip -- `ordering = 2` for scenes of MORE THAN 32 analytic primitives, any number: whole paths in ONE launch per
+// group of iterations, with every expensive step on dense, type-pure waves.
 //
 // The nearest-hit loop it replaces is type- and count-agnostic (/root/reference/src/raytraceKernel.cu:134-153: every
-// primitive, first strictly nearer wins, ties to the lower index).  The lock-step kernel for these scenes
-// (k_bounce_seg<WIDE>, pt_k_seg.hip) finds the same hits with a two-level culling, but its per-lane loops leave the
-// wave mostly idle (cluster walk at 24 of 64 lanes, exact cube tests at 22, exact sphere tests at 7:
-// profiles/r02i_cullstats_c4.log), and its wave-uniform pass over every cluster box is paid by every ray wherever it
-// goes.  Here a ray only meets the primitives near its own path, and the unit of work is no longer "a ray":
+// primitive, first strictly nearer wins, ties to the lower index; any numberOfGeoms, :192-194).  The lock-step kernel for
+// these scenes (k_bounce_seg, pt_k_seg.hip) finds the same hits with wave-uniform passes over the bounds -- all of them beyond
+// 256 primitives -- and per-lane loops that leave the wave mostly idle.  Here a ray only meets the primitives near its own
+// path, and the unit of work is no longer "a ray":
 //
 //   FRESH   64 rays (the top of the wave's stack of survivors, or a job of camera rays) take a RAY SLOT each in the
 //           wave's LDS region (origin + direction, an 8-entry candidate list, best depth / hit so far) and park
 //           throughput, pixel word and level in the slot's payload record in global memory.  The few BIG primitives
 //           (walls: listed in too many cells to be worth a grid entry) have their bounds tested by every ray in a
 //           wave-uniform loop.
+//           CAMERA GROUPS (up to 256 primitives): the 64 rays share their origin and span a degree or two, so instead of 64
+//           walks the wave tests every primitive's bound once against the group's CONE and the PLANE of its fan (lane = one
+//           primitive; pt_kernels.hpp, fan_*), and only the handful it meets have their bounds tested by the rays.
 //   WALK    every ray steps through the cells of a uniform grid over the small primitives (3D-DDA, one cell per
 //           trip; boundaries are rebuilt from the integer cell index, never accumulated).  A step into a non-empty
 //           cell leaves a (ray, cell, axes stepped) entry in a small LDS buffer.
@@ -22,7 +24,7 @@
 //           second buffer; unless the reference is its cell's last, the entry returns to the buffer for the next
 //           one (so a crowded cell never holds a wave in a loop).
 //   BOUNDS  64 (ray, primitive) entries of one type, lane = one entry: gather the ray from its slot, test the
-//           primitive's own conservative bound, append a candidate to the ray's list as a 16-bit key (quantised
+//           primitive's own conservative bound, append a candidate to the ray's list as a key (quantised
 //           conservative entry distance, id).
 //   SELECT  every ray picks its nearest candidate (smallest key) and waits on one of two wave-private stacks of slot
 //           ids by that candidate's TYPE.  A ray whose list overflowed (> 8 candidates: rare), or that cannot be
@@ -32,17 +34,25 @@
 //           far is kept as (depth, id, face) in the slot.  Then the next candidate that could still win or tie -- key
 //           distance not beyond the best hit -- is selected by a branch-free scan of the 8 keys (no re-evaluation of
 //           bounds), and the ray goes back on the stack of THAT candidate's type (hit point and normal of a winning
-//           test go to the payload record meanwhile).  A ray without such a candidate is finished: shaded at once
-//           (RNG stream of its own level, scatter, emitters -> memory-side float atomics), its slot freed, a survivor
-//           pushed on the wave's stack in global memory for the next bounce.
+//           test go to the payload record meanwhile).  A finished ray frees its slot; with a hit its payload record waits
+//           for the shading of that TYPE of primitive.
+//   SHADE   pops 64 payload records of one hit type: RNG stream of the ray's own level, scatter, emitters -> memory-side
+//           float atomics; a survivor goes on one of three stacks in global memory by the length of the walk ahead of it.
+//
+// Two id formats, one source (template parameter BIG):
+//   narrow (33..256 primitives)  byte ids, 16-bit keys and references; the geometry table (37 KB at 256) and the grid are staged
+//                                in LDS beside the waves' regions;
+//   wide   (more than 256)       ids of up to 21 bits, 32-bit keys (10-bit distance, type, id) and references; the geometry is
+//                                gathered from the device array through the vector cache, the grid is staged in LDS when it fits
+//                                beside the waves' regions (about 1 100 primitives) and read from global memory otherwise.
 //
 // WALK, CELLS and BOUNDS interleave under one wave-uniform dispatcher: a buffer is drained whenever it holds 64
 // entries, so every stage but the walk itself runs on full waves whatever a single ray meets.  Nothing leaves the
-// wave: no barrier, no inter-wave traffic, no pools.  One 1024-thread block per CU shares the 37-KB geometry table
-// and the grid (variants: fewer waves with more ray slots each).  Results are the reference loop's: the cells are
-// filled with margins far above the walk's float error, so every primitive whose bound the ray enters is found, and
-// every candidate entered before the best hit is tested exactly; image, live counts and emitter hits equal every
-// other kernel's bit for bit (tests/test_gpu_parity.py, tests/test_gpu_round3.py).
+// wave: no barrier, no inter-wave traffic, no pools.  One 1024-thread block per CU shares the tables and the grid.
+// Results are the reference loop's: the cells are filled with margins far above the walk's float error, so every primitive
+// whose bound the ray enters is found, and every candidate entered before the best hit is tested exactly; image, live counts,
+// emitter hits and ray records equal every other kernel's bit for bit (tests/test_gpu_parity.py,
+// tests/test_gpu_whole_paths_and_bench.py, tests/test_gpu_many_primitives.py; the index itself: tests/test_grid_cpu.py).
 #include "pt_kernels.hpp"
 
 namespace ptk {

@@ -2,7 +2,7 @@
 // blocks, the LDS table layout, the culling arithmetic and the nearest-hit loops, and the host-callable launchers
 // each family exports.  One translation unit per family:
 //
-//   pt_k_seg.hip    k_bounce_seg   stable order (library default): one wave streams its pool segments 64 rays at a
+//   pt_k_seg.hip    k_bounce_seg   stable order (ordering = 0; the parity hooks' reference): one wave streams its pool segments 64 rays at a
 //                                  time: [bounce 0: camera ray] -> candidate culling -> exact reference tests ->
 //                                  scatter -> accumulate -> ballot/mbcnt compaction into the output segment.
 //                                  Variants: NEE (direct light), WIDE (33..256 primitives), meshes.  + k_generate
@@ -10,11 +10,12 @@
 //   pt_k_queue.hip  k_bounce_q     ordering = 1, <= 32 primitives: two wave-private stages with LDS work queues by
 //                                  candidate type, one launch per bounce
 //   pt_k_path.hip   k_path_q       ordering = 2, <= 32 primitives: whole paths on the typed work queues, one launch
-//                                  per group of iterations (what bench.py, the adaptor and ptrender run)
-//   pt_k_wide.hip   k_path_w       ordering = 2, 33..256 primitives: whole paths; a grid walk feeds dense (ray, cell) and
+//                                  per group of iterations (pt_config_default: what bench.py, the adaptor and ptrender run)
+//   pt_k_wide.hip   k_path_w       ordering = 2, more than 32 analytic primitives (any number): whole paths; a grid walk feeds dense (ray, cell) and
 //                                  (ray, primitive) pairs, type-pure exact tests on full waves
 //   pt_k_misc.hip   k_fold, k_flat (the reference kernel as shipped + primary-hit hook), k_display, KAT kernels
-//   pt_api.hip      contexts, scene upload, the C ABI of include/ptmi355.h
+//   pt_api.hip      contexts, scene upload, launch planning, the C ABI of include/ptmi355.h
+//   pt_build.cpp    host-only scene builders: culling bounds, k_path_w's grid, clusters, mesh BVHs (no device code)
 //
 // No CPU fallback lives anywhere here: every entry point needs a gfx950 device.
 #pragma once
@@ -673,7 +674,7 @@ struct PathArgs {
     uint32_t static_rounds;          // every wave's first jobs are its own (job = round * waves + slot): device atomics on ONE
                                      //   address are served memory-side at ~8 ns each, so only the last part of a launch is drawn
     uint32_t *error;
-    uint32_t turn_limit;             // scheduling turns a wave may take before it gives up with error 3 (2^24: never reached; tests lower it)
+    uint32_t turn_limit;             // scheduling turns a wave may take before it gives up with error 3 (the host prices it at the worst case of the launch x 4: pt_api.hip; tests lower it)
     float qscale, slack_max;         // k_path_w: candidate keys carry floor(entry distance * qscale); largest GeomRec::slack of the scene
     // parity hook (pt_debug_trace_pool with ordering = 2): rays that survive bounce tap_level - 1 are written here (10 fields, SoA,
     // stride tap_cap, in the order the waves meet them; the host sorts them by pixel) instead of going on to their next bounce
@@ -683,7 +684,7 @@ struct PathArgs {
 };
 constexpr uint32_t kWPayload = 16;   // k_path_w: floats per payload record in global memory: one 64-byte line per ray (layout: pt_k_wide.hip)
 
-// k_path_w's spatial index: a uniform grid over the SMALL analytic primitives (host: build_grid, pt_api.hip).  A ray
+// k_path_w's spatial index: a uniform grid over the SMALL analytic primitives (host: build_grid, pt_build.cpp).  A ray
 // walks the cells it crosses (3D-DDA) and only the primitives listed there have their own bounds tested; primitives
 // that would be listed in more than kGridBigCells cells (walls, floors) wait in a short list every ray tests.
 // Blob, staged in LDS behind the geometry table: cells[ncells] (first ref | count << 16), refs[nrefs] (16 bits each),
