@@ -231,7 +231,7 @@ def main():
     ap.add_argument("--streams", type=int, default=0,
                     help="contexts per GPU, each on its own HIP stream and owning every (streams*gpus)-th row: the tails of one "
                          "context's launches are filled by the other's (bit-identical, like the multi-GPU sharding); 1 = off; "
-                         "0 = auto: 2 when a rank renders at least 30 M camera rays per timed pass, else 1 (measured: tools/shard_sim.py)")
+                         "0 = auto: 2 when a rank renders at least 30 M camera rays per timed pass (100 M on k_path_w's scenes), else 1 (measured: tools/shard_sim.py)")
     ap.add_argument("--direct-light", type=int, default=0, help="1 = next-event estimation (one shadow ray per diffuse hit); not the headline configuration")
     ap.add_argument("--warm-passes", type=int, default=0, help="untimed K-step passes before the timed ones (0 = until the pass time has settled; profiling runs fix it)")
     ap.add_argument("--dump-image", default="", help="rank 0 writes the frame it holds after the per-frame exchange (float32 .npy, H x W x 3): parity tests of the N > 1 path")
@@ -307,9 +307,10 @@ def main():
 
     # S streams per GPU (pt_config.streams): the context shards this rank's rows once more over S internal contexts,
     # each on its own HIP stream, all rendering straight into the same device accumulator.
-    # (k_path_w, scenes of 33..256 primitives, fills every CU's LDS with one block, so a second context's blocks only start where
-    # the first one's have finished -- which is what hides the first launch's drain: configs[3] 0.948 -> 0.932 ms/step with two)
-    S = args.streams if args.streams > 0 else (2 if (W * H // world) * args.steps >= 30_000_000 else 1)
+    # k_path_w (more than 32 primitives: one block fills a CU's LDS, so a second context's blocks only start where the first one's have
+    # finished) gains from the second stream only on long passes: configs[3] 0.865 with one stream against 0.879 with two at 20
+    # steps, 0.846 against 0.840 at 192 (in-call pairs, round 4); k_path_q from 30 M camera rays per pass on
+    S = args.streams if args.streams > 0 else (2 if (W * H // world) * args.steps >= (30_000_000 if len(geoms) <= 32 else 100_000_000) else 1)
     accum = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda:%d" % device)
     tracer = pkg.PathTracer(pkg.default_config(device=device, max_depth=depth, row_offset=rank, row_stride=world, streams=S,
                                                chunk_rays=args.chunk_rays, blocks_per_cu=args.blocks_per_cu, culling=args.culling, batch=args.batch,
