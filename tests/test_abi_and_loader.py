@@ -89,7 +89,7 @@ def test_product_tree_never_references_the_oracle():
     assert "oracle" not in hdr
 
 
-SCENES = ["cornell", "cornell_c1", "cornell_mirror", "cornell_glass_4k", "random256"]
+SCENES = ["cornell", "cornell_c1", "cornell_mirror", "cornell_glass_4k", "random256", "random1024"]
 
 
 @pytest.mark.parametrize("name", SCENES)

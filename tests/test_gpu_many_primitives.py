@@ -36,6 +36,15 @@ def test_more_than_256_primitives_match_the_oracle(pt, extra, kw):
     st = tr.stats()
     assert [st.live[k] for k in range(depth + 1)] == [int(v) for v in live], (sc.G, kw)
     assert np.array_equal(tr.image(), want), (sc.G, kw)
+    if kw["ordering"] == 2:
+        # whole paths on k_path_w with wide ids, whatever the count: the grid staged in LDS while it fits beside the waves' regions
+        # (257 and 600 primitives), read from global memory beyond that (1 500: its blob alone exceeds what is left of the CU's LDS)
+        shape = tr.path_shape()
+        assert shape["family"] == "k_path_w" and shape["waves_per_block"] == 16, shape
+        if sc.G == 1500:
+            assert shape["lds_bytes"] < 140 * 1024 and shape["records_per_wave"] == 96, shape
+        else:
+            assert shape["lds_bytes"] > 140 * 1024, shape
     if kw.get("streams", 1) == 1:
         n, arrs, pix = tr.trace_pool(2, 3)
         order = np.argsort(pix, kind="stable")
@@ -88,3 +97,32 @@ def test_camera_groups_on_wide_frames_match_the_oracle(pt, extra, w, h, kw):
         pix, arrs = pix[order], [x[order] for x in arrs]
         assert n == on and np.array_equal(pix, opix) and all(np.array_equal(a, b) for a, b in zip(arrs, oarrs)), (extra, w, kw)
     tr.close()
+
+
+def test_1024_primitive_bench_scene_full_size_slices(pt):
+    """bench.py --workload c1k (scenes/random1024.txt at its own 1920 x 1080, 8 bounces): the whole-path kernel with wide ids on two
+    streams against the oracle on a thin interleave of rows, and against the stable per-bounce kernels' live counts."""
+    sc = orc.load_golden_scene("random1024")
+    assert (sc.W, sc.H, sc.G) == (1920, 1080, 1024)
+    tr = make_tracer(sc, ordering=2, streams=2)
+    tr.set_image(None); tr.render(1, 2)
+    full = tr.image()
+    st = tr.stats()
+    assert st.live[0] == 2 * 1920 * 1080 and all(st.live[k] >= st.live[k + 1] for k in range(8))
+    want, _ = orc.render(sc, oracle_config(8, row_offset=7, row_stride=360), 1, 2)
+    rows = np.arange(1080) % 360 == 7
+    assert np.array_equal(full[rows], want[rows])
+    tr.close()
+
+
+def test_5006_primitives_match_the_oracle(pt):
+    """far beyond the byte ids: 5 006 primitives (17 x 17 x 17 cells and tens of thousands of references in global memory)"""
+    sc = orc.many_primitives_scene(5000, w=96, h=54, size=(0.05, 0.25))
+    want, live = orc.render(sc, oracle_config(5), 1, 2)
+    for kw in (dict(ordering=2), dict(ordering=2, streams=2, batch=1), dict(ordering=0)):
+        tr = make_tracer(sc, depth=5, **kw)
+        tr.set_image(None); tr.render(1, 2)
+        st = tr.stats()
+        assert [st.live[k] for k in range(6)] == [int(v) for v in live], kw
+        assert np.array_equal(tr.image(), want), kw
+        tr.close()
