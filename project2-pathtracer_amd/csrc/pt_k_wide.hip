@@ -587,15 +587,73 @@ __global__ __launch_bounds__(WAVES * 64) void k_path_w(SegArgs a, PathArgs pa, G
                             const f3 dd = mk(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
                             float bd = kInf;
                             int bh = -1;
-                            for (int k = (int)lane; k < a.G; k += 64) {
-                                const GeomRec *g = lg + k;
-                                const int ty = g->type;
-                                const bool pb = ty == 1, psph = ty == 0;
-                                float depth = -1.0f;
-                                f3 P, N;
-                                if (__any(pb)) { if (pb) depth = box_test(g->inv, g->xf, g->inside_hits, oo, dd, P, N); }
-                                if (__any(psph)) { if (psph) depth = sphere_test(g->inv, g->xf, oo, dd, P, N); }
-                                if (depth > -PT_EPSILON && (depth < bd || (depth == bd && k < bh))) { bd = depth; bh = k; }
+                            if constexpr (!BIG) {                                   // up to 256 primitives: four trips
+                                for (int k = (int)lane; k < a.G; k += 64) {
+                                    const GeomRec *g = lg + k;
+                                    const int ty = g->type;
+                                    const bool pb = ty == 1, psph = ty == 0;
+                                    float depth = -1.0f;
+                                    f3 P, N;
+                                    if (__any(pb)) { if (pb) depth = box_test(g->inv, g->xf, g->inside_hits, oo, dd, P, N); }
+                                    if (__any(psph)) { if (psph) depth = sphere_test(g->inv, g->xf, oo, dd, P, N); }
+                                    if (depth > -PT_EPSILON && (depth < bd || (depth == bd && k < bh))) { bd = depth; bh = k; }
+                                }
+                            } else {
+                            // first every primitive's BOUND against this ray (lane = primitive; the pair buffers are empty here: the
+                            // second one takes the ids, cubes from the bottom, spheres from the top), then the exact tests of the few that
+                            // pass on dense lanes.  A ray whose bounds nearly all pass (non-finite: false comparisons keep everything)
+                            // takes the plain loop over all primitives.
+                            const CullRay pr = make_cull_ray(oo, dd);
+                            uint32_t nb2 = 0u, ns2 = 0u;
+                            bool fits = true;
+                            for (int base = 0; base < a.G && fits; base += 64) {
+                                const int k = base + (int)lane;
+                                bool pb = false, psph = false;
+                                if (k < a.G) {
+                                    const GeomRec *g = lg + k;
+                                    const int ty = g->type;
+                                    float tn;
+                                    if (ty == 1) pb = cull_box(g->bmin, g->bmax, pr, tn);
+                                    else if (ty == 0) psph = cull_sphere(g->bmin, g->bmax, pr, tn);
+                                }
+                                const u64 cb2 = __ballot(pb), sb2 = __ballot(psph);
+                                const uint32_t cn = (uint32_t)__popcll(cb2), sn = (uint32_t)__popcll(sb2);
+                                if (nb2 + ns2 + cn + sn > kBufC) { fits = false; break; }
+                                if (pb) bufC[nb2 + wave_rank(cb2)] = (uint32_t)k;
+                                if (psph) bufC[kBufC - 1u - (ns2 + wave_rank(sb2))] = (uint32_t)k;
+                                nb2 += cn; ns2 += sn;
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                            if (fits) {
+                                for (uint32_t i = lane; i < nb2; i += 64u) {
+                                    const int k = (int)bufC[i];
+                                    const GeomRec *g = lg + k;
+                                    f3 P, N;
+                                    const float depth = box_test(g->inv, g->xf, g->inside_hits, oo, dd, P, N);
+                                    if (depth > -PT_EPSILON && (depth < bd || (depth == bd && k < bh))) { bd = depth; bh = k; }
+                                }
+                                for (uint32_t i = lane; i < ns2; i += 64u) {
+                                    const int k = (int)bufC[kBufC - 1u - i];
+                                    const GeomRec *g = lg + k;
+                                    f3 P, N;
+                                    const float depth = sphere_test(g->inv, g->xf, oo, dd, P, N);
+                                    if (depth > -PT_EPSILON && (depth < bd || (depth == bd && k < bh))) { bd = depth; bh = k; }
+                                }
+                            } else {
+                                for (int k = (int)lane; k < a.G; k += 64) {
+                                    const GeomRec *g = lg + k;
+                                    const int ty = g->type;
+                                    const bool pb = ty == 1, psph = ty == 0;
+                                    float depth = -1.0f;
+                                    f3 P, N;
+                                    if (__any(pb)) { if (pb) depth = box_test(g->inv, g->xf, g->inside_hits, oo, dd, P, N); }
+                                    if (__any(psph)) { if (psph) depth = sphere_test(g->inv, g->xf, oo, dd, P, N); }
+                                    if (depth > -PT_EPSILON && (depth < bd || (depth == bd && k < bh))) { bd = depth; bh = k; }
+                                }
+                            }
+                            __builtin_amdgcn_wave_barrier();                      // the ids are read before the next ray's overwrite them
                             }
 #pragma unroll
                             for (int sft = 32; sft > 0; sft >>= 1) {             // nearest wins, ties to the lower index
