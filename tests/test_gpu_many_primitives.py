@@ -126,3 +126,75 @@ def test_5006_primitives_match_the_oracle(pt):
         assert [st.live[k] for k in range(6)] == [int(v) for v in live], kw
         assert np.array_equal(tr.image(), want), kw
         tr.close()
+
+
+@pytest.mark.parametrize("kind", ["cubes only", "spheres only, no room", "scaled x 37", "scaled x 0.05", "all in one spot", "glass and mirrors only"])
+def test_wide_ids_on_other_kinds_of_scenes(pt, kind):
+    """The wide-id form of k_path_w beyond the random room: one primitive type only (an empty typed stack), no enclosing room
+    (most rays leave without a candidate), other scene scales (the grid's margins and the keys' distance steps are relative),
+    hundreds of primitives piled into a few cells (long reference lists, lists that overflow), specular materials only (long
+    paths: every bounce survives)."""
+    import ctypes as C
+    base = orc.many_primitives_scene(594, w=128, h=72)
+    geoms, cam = list(base.geoms), base.camera
+    if kind == "cubes only":
+        geoms = [g for g in geoms if g.type == 1]
+    elif kind == "spheres only, no room":
+        geoms = [g for g in geoms[6:] if g.type == 0]
+    elif kind.startswith("scaled"):
+        f = float(kind.split("x")[1])
+        sc2 = orc.many_primitives_scene(594, w=128, h=72)
+        # rebuild every transform at the new scale with the oracle's transform builder (translation and scale multiplied)
+        rng = np.random.default_rng(565)
+        geoms = []
+        xf, inv = np.zeros(16, np.float32), np.zeros(16, np.float32)
+        gold = __import__("json").load(open(__import__("os").path.join(orc.GOLD, "ref_scene_random256.json")))
+        for o, g0 in zip(gold["objects"][:6], sc2.geoms[:6]):
+            fr = o["frames"][0]
+            t = [orc.f32_from_bits(v) * f for v in fr["translation"]]; r = [orc.f32_from_bits(v) for v in fr["rotation"]]; sc_ = [orc.f32_from_bits(v) * f for v in fr["scale"]]
+            orc.lib().orc_build_transform(orc.vec3(*t), orc.vec3(*r), orc.vec3(*sc_), orc.fptr(xf), orc.fptr(inv))
+            g = orc.Geom(); g.type, g.materialid = g0.type, g0.materialid
+            for k in range(16):
+                g.transform[k] = float(xf[k]); g.inverseTransform[k] = float(inv[k])
+            geoms.append(g)
+        for i in range(594):
+            c = [float(np.float32(v)) * f for v in (rng.uniform(-4.6, 4.6), rng.uniform(0.4, 9.2), rng.uniform(-4.6, 4.6))]
+            sz = float(np.float32(rng.uniform(0.12, 0.5))) * f
+            rot = [float(np.float32(v)) for v in rng.uniform(0, 360, 3)] if i & 1 else [0.0, 0.0, 0.0]
+            orc.lib().orc_build_transform(orc.vec3(*c), orc.vec3(*rot), orc.vec3(sz, sz, sz), orc.fptr(xf), orc.fptr(inv))
+            g = orc.Geom(); g.type, g.materialid = (1 if i & 1 else 0), i % 7
+            for k in range(16):
+                g.transform[k] = float(xf[k]); g.inverseTransform[k] = float(inv[k])
+            geoms.append(g)
+        cam = orc.Camera()
+        C.memmove(C.byref(cam), C.byref(base.camera), C.sizeof(orc.Camera))
+        for k in range(3):
+            cam.position[k] = base.camera.position[k] * f
+    elif kind == "all in one spot":
+        rng = np.random.default_rng(7)
+        xf, inv = np.zeros(16, np.float32), np.zeros(16, np.float32)
+        geoms = list(base.geoms[:6])
+        for i in range(400):
+            c = [float(np.float32(v)) for v in (rng.uniform(-0.6, 0.6), rng.uniform(4.0, 5.2), rng.uniform(-0.6, 0.6))]
+            sz = float(np.float32(rng.uniform(0.2, 0.6)))
+            orc.lib().orc_build_transform(orc.vec3(*c), orc.vec3(0.0, 0.0, 0.0), orc.vec3(sz, sz, sz), orc.fptr(xf), orc.fptr(inv))
+            g = orc.Geom(); g.type, g.materialid = (1 if i % 3 == 0 else 0), i % 7
+            for k in range(16):
+                g.transform[k] = float(xf[k]); g.inverseTransform[k] = float(inv[k])
+            geoms.append(g)
+    elif kind == "glass and mirrors only":
+        geoms = [g for g in geoms]
+        for g in geoms[6:]:
+            g.materialid = 3 if g.materialid % 2 else 6             # (random256's materials: 3 mirror, 6 glass)
+    sc = orc.Scene(geoms, base.materials, cam)
+    assert sc.G > 256
+    depth, iters = 6, 2
+    want, live = orc.render(sc, oracle_config(depth), 1, iters)
+    for kw in (dict(ordering=2), dict(ordering=2, streams=2, batch=1)):
+        tr = make_tracer(sc, depth=depth, **kw)
+        tr.set_image(None); tr.render(1, iters)
+        st = tr.stats()
+        assert tr.path_shape()["family"] == "k_path_w"
+        assert [st.live[k] for k in range(depth + 1)] == [int(v) for v in live], (kind, kw)
+        assert np.array_equal(tr.image(), want), (kind, kw)
+        tr.close()
