@@ -1,8 +1,12 @@
 #!/bin/bash
 # round 4, final measurement set on the final tree: the -m gpu suite + smoke, the bench lines of every workload (the driver's
-# command first), profiles of the workloads not yet profiled on these kernel sources
+# command first), then the rocprofv3 profiles of every workload (tools/r4_profiles.sh) -- two gpurun calls: `final` and `profiles`
 set -u
 OUT=gpurun_out; mkdir -p $OUT
+if [ "${1:-final}" = "profiles" ]; then
+  bash tools/r4_profiles.sh c3 c4 c5 c1k mesh mesh5k || exit 1
+  exit 0
+fi
 bash tools/gpu_check.sh r04z \
   "driver:--gpus 1 --steps 20 --warmup 5" \
   "c3_192:" \
@@ -15,4 +19,3 @@ bash tools/gpu_check.sh r04z \
   "mesh5k:--workload mesh5k --no-cpu-baseline" \
   "nee:--direct-light 1 --no-cpu-baseline" \
   "nee_o2:--direct-light 1 --ordering 2 --no-cpu-baseline" || exit 1
-bash tools/r4_profiles.sh c5 mesh mesh5k || exit 1
