@@ -112,8 +112,8 @@ typedef struct {
                                 about 96 M rays per launch for the whole-path kernels, 32 M for the per-bounce kernels, whose two
                                 ray pools grow with it; at most 128 iterations).  Results are identical: each in-flight iteration
                                 accumulates into its own plane of the owned pixels (12 bytes each: up to 1.15 GB per stream at
-                                1080p with the auto group, never more than 4 GiB) and the planes are folded into the image in
-                                iteration order. */
+                                1080p with the auto group, never more than 4 GiB or a quarter of the free device memory) and the
+                                planes are folded into the image in iteration order. */
     int   ordering;          /* which kernel family renders; results are identical.
                                 2 = whole paths, ONE launch per group of iterations (pt_config_default): waves draw jobs of camera
                                     rays and keep every ray from the camera to its end; up to 32 primitives on typed work queues

@@ -640,8 +640,12 @@ int pt_upload_scene(pt_context *c, const pt_geom *geoms, int G, const pt_materia
             else if (whole_path) K = (uint32_t)((96u * 1024u * 1024u) / n_own);     // configs[4] (4K): 20 iterations per launch 0.925, 10: 0.929, 4: 0.952 ms/step
             else K = (uint32_t)((32u * 1024u * 1024u) / n_own);      // 16 at 1080p: measured best (14: +4 %, 18: +8 % time)
             // the slot field has 7 bits beside the count-emission flag; a plane holds the owned pixels: <= 4 GiB in all
+            // ... and never more than a quarter of the device memory that is free right now (several contexts and streams share a GPU)
             const uint64_t plane_bytes = (uint64_t)n_own * 3 * sizeof(float);
-            const uint32_t by_memory = (uint32_t)((4ull << 30) / plane_bytes);
+            uint64_t plane_budget = 4ull << 30;
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (uint64_t)free_b / 4u < plane_budget) plane_budget = (uint64_t)free_b / 4u;
+            const uint32_t by_memory = (uint32_t)(plane_budget / plane_bytes);
             if (K > 128u) K = 128u;
             if (K > by_memory) K = by_memory;
             if (K < 1u) K = 1u;
