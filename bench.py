@@ -272,8 +272,14 @@ def main():
     ndev = torch.cuda.device_count()
     device = local_rank % ndev
     torch.cuda.set_device(device)
-    if world > 1:
+    # PT_BENCH_DIST=1: run the N > 1 code -- process group, barriers, the all-reduce of the pass time, the per-frame exchange -- with
+    # a world of ONE rank as well (a rehearsal of the RCCL calls on a box with one GPU: tests/; never the driver's command)
+    dist_on = world > 1 or os.environ.get("PT_BENCH_DIST", "0") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            import socket
+            sk = socket.socket(); sk.bind(("127.0.0.1", 0)); os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1])); sk.close()
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     pkg = importlib.import_module("project2-pathtracer_amd")
@@ -322,23 +328,23 @@ def main():
     tracer.bind_device_image(accum)
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
 
     # warm-up (untimed)
     tracer.render(1, args.warmup)
     tracer.sync()
-    row_gather = RowGather(accum if backend == "nccl" else accum.cpu(), H, W)     # buffers allocated once, outside any timed region
+    row_gather = RowGather(accum if backend == "nccl" else accum.cpu(), H, W, force=dist_on)     # buffers allocated once, outside any timed region
 
     def exchange(t):
-        return row_gather(t) if args.exchange == "gather" else reduce_to_root(t)
+        return row_gather(t) if args.exchange == "gather" else reduce_to_root(t, force=dist_on)
 
-    if world > 1 and backend == "nccl":
+    if dist_on and backend == "nccl":
         exchange(accum.clone())                # RCCL communicator setup outside the timed region
     torch.cuda.synchronize()
 
     def max_over_ranks(dt):
-        if world > 1:
+        if dist_on:
             t = torch.tensor([dt], dtype=torch.float64, device=("cuda:%d" % device) if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -395,10 +401,10 @@ def main():
     elapsed = passes[order[R // 2]] if R % 2 else 0.5 * (passes[order[R // 2 - 1]] + passes[order[R // 2]])
     raw = tracer.stats()                          # counters of the last pass: every pass renders the same iterations
     # N > 1: the frame exchange, once per frame (see the module docstring); three measurements, the median counts
-    exchange_s = sorted(timed_exchange() for _ in range(3))[1] if world > 1 else 0.0
+    exchange_s = sorted(timed_exchange() for _ in range(3))[1] if dist_on else 0.0
     if args.dump_image and rank == 0:
         import numpy as np
-        frame = gathered[0] if world > 1 else accum
+        frame = gathered[0] if dist_on else accum
         np.save(args.dump_image, frame.detach().cpu().numpy().reshape(H, W, 3))
     frame_iterations = max(int(sf.iterations), args.steps)
     elapsed_frame_share = elapsed + exchange_s * args.steps / frame_iterations
@@ -412,7 +418,7 @@ def main():
     import types
     stats = types.SimpleNamespace(live=[int(raw.live[k]) for k in range(65)], emitted=int(raw.emitted), iterations=int(raw.iterations),
                                   bounce_launches=int(raw.bounce_launches))
-    if world > 1:                                 # whole-job counters: the live rays / emitter hits of every rank's rows
+    if dist_on:                                   # whole-job counters: the live rays / emitter hits of every rank's rows
         t = torch.tensor(stats.live + [stats.emitted, stats.bounce_launches], dtype=torch.int64, device=("cuda:%d" % device) if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         t = [int(v) for v in t.tolist()]
@@ -537,10 +543,10 @@ def main():
                        "warmup_passes": "W steps + %d untimed K-step passes (same launch-group shape as the timed passes; until three in a row agree to 1 %%)" % warm_passes},
             "roofline": roof,
         }
-        if world > 1:
+        if dist_on:
             result["exchange"] = {
                 "kind": "gather of the owned rows on rank 0" if args.exchange == "gather" else "full-frame reduce(sum) to rank 0",
-                "backend": "RCCL over xGMI" if backend == "nccl" else backend + " (CPU rehearsal)",
+                "backend": ("RCCL over xGMI" if backend == "nccl" else backend + " (CPU rehearsal)") + (" -- a world of ONE rank (PT_BENCH_DIST=1: rehearsal of the calls, nothing crosses a link)" if world == 1 else ""),
                 "ms": round(exchange_s * 1e3, 4), "measured": "median of 3, barrier + synchronize on both sides, max over ranks, right after the timed passes",
                 "bytes_received_by_rank0": int(W * H * 12 * (world - 1) / world) if args.exchange == "gather" else W * H * 12,
                 "once_per": "frame = %d iterations (the scene's ITERATIONS)" % frame_iterations,
@@ -556,7 +562,7 @@ def main():
             result["cpu_baseline"] = cpu_baseline(scene_file, depth, options=options) if not meshes else None    # the oracle's mesh entry point is exercised in tests/, not timed here
         print(json.dumps(result), flush=True)
     tracer.close()
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
     return result
 

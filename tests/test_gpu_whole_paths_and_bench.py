@@ -247,3 +247,22 @@ def test_exchange_code_runs_under_rccl_with_one_rank(pt, tmp_path):
     sc = orc.load_golden_scene("cornell_mirror").with_resolution(96, 55)
     want, _ = orc.render(sc, oracle_config(6), 1, 3)
     assert np.array_equal(np.load(out), want)
+
+
+@pytest.mark.parametrize("exchange", ["gather", "reduce"])
+def test_bench_runs_its_own_multi_gpu_code_under_rccl_with_one_rank(pt, tmp_path, exchange):
+    """bench.py itself with PT_BENCH_DIST=1: the N > 1 code of main() -- init_process_group(backend nccl = RCCL), the barriers, the
+    all-reduce of the pass time and of the counters, the timed per-frame exchange on device tensors -- runs with a world of one rank
+    on this box's GPU; the line carries the exchange block and the dumped frame is the oracle's."""
+    out = str(tmp_path / "frame.npy")
+    env = dict(os.environ, PT_BENCH_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--repeats", "2", "--resolution", "320x180",
+                        "--no-cpu-baseline", "--exchange", exchange, "--dump-image", out], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert res["n_gpus"] == 1 and "RCCL" in res["exchange"]["backend"] and "ONE rank" in res["exchange"]["backend"]
+    assert res["exchange"]["ms"] > 0 and res["value_if_exchanged_every_pass"] < res["value"] * 1.0001
+    sc = orc.load_golden_scene("cornell_mirror").with_resolution(320, 180)
+    want, _ = orc.render(sc, oracle_config(8), 3, 4)              # the timed passes render iterations warmup + 1 .. warmup + steps
+    assert np.array_equal(np.load(out), want)
