@@ -198,3 +198,25 @@ def test_wide_ids_on_other_kinds_of_scenes(pt, kind):
         assert [st.live[k] for k in range(depth + 1)] == [int(v) for v in live], (kind, kw)
         assert np.array_equal(tr.image(), want), (kind, kw)
         tr.close()
+
+
+def test_tables_that_leave_no_room_for_k_path_w_fall_back_to_the_per_bounce_kernels(pt):
+    """256 primitives with 1 400 materials: the tables alone take 105 KB of a CU's LDS, no block shape of k_path_w fits beside them,
+    and pt_upload_scene says so BEFORE it sizes launch groups and pools -- the scene renders on the per-bounce kernels, bit-exact,
+    instead of failing the upload (advisor, round 3)."""
+    import copy
+    base = orc.load_golden_scene("random256").with_resolution(160, 90)
+    mats = [copy.copy(base.materials[i % base.M]) for i in range(1400)]
+    geoms = list(base.geoms)
+    for i, g in enumerate(geoms):
+        g.materialid = g.materialid + base.M * (i % 150)          # the same material, 150 copies further on
+    sc = orc.Scene(geoms, mats, base.camera)
+    want, live = orc.render(sc, oracle_config(6), 1, 2)
+    for kw in (dict(ordering=2), dict(ordering=2, streams=2)):
+        tr = make_tracer(sc, depth=6, **kw)
+        assert tr.path_shape()["family"] == "per-bounce"
+        tr.set_image(None); tr.render(1, 2)
+        st = tr.stats()
+        assert [st.live[k] for k in range(7)] == [int(v) for v in live], kw
+        assert np.array_equal(tr.image(), want), kw
+        tr.close()
